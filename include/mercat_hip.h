@@ -1,0 +1,133 @@
+/* mercat_hip.h -- C ABI of libmercat_hip.so: the MI355X (gfx950) k-mer counting engine that
+ * stands in for MerCat2's counting path.
+ *
+ * Drop-in boundary (reference file:line, relative to the reference checkout):
+ *   find_kmers(file, kmer, min_count) -> {kmer: count}      lib/mercat2_kmers.py:32-78
+ *   run_mercat2(basename, files, out_file, kmer, min_count) bin/mercat2.py:115-137
+ *   chunk_files / Chunker.stream_delim                      bin/mercat2.py:86-106, lib/mercat2_Chunker.py:39-59
+ * The Python host layer (mercat2_amd/) mirrors those three callables on top of this ABI with
+ * ctypes; INTEGRATION.md shows the stub a MerCat2 maintainer would add.
+ *
+ * Conventions: every function returns an int status (MK_OK == 0, negative = error); the text
+ * of the last error of a context is mk_last_error(ctx).  The caller owns every buffer it
+ * passes in or receives into; a context owns its device memory and its HIP stream.  A context
+ * is not thread-safe; different contexts may be used from different host threads.  There is
+ * no CPU fallback anywhere behind this ABI: without a usable HIP device mk_create fails.
+ */
+#ifndef MERCAT_HIP_H
+#define MERCAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MK_OK 0
+#define MK_ERR_ARG (-1)       /* bad argument (k < 1, unknown alphabet, null pointer, ...) */
+#define MK_ERR_HIP (-2)       /* a HIP runtime call failed (message has the call and hipError) */
+#define MK_ERR_NOMEM (-3)     /* device or host allocation failed */
+#define MK_ERR_STATE (-4)     /* call sequence error (feed outside begin/end, ...) */
+#define MK_ERR_NON_ASCII (-5) /* input holds bytes >= 0x80: the reference would decode them as
+                                 multi-byte characters; refused rather than counted wrongly */
+#define MK_ERR_IO (-6)        /* file could not be written */
+#define MK_ERR_RANGE (-7)     /* caller buffer too small / value out of range */
+
+/* Alphabets select the packed fast path; they never restrict the input.  Windows holding a
+ * symbol outside the alphabet are still counted, exactly, by the by-reference kernel
+ * (the reference counts "any character": lib/mercat2_kmers.py:56-60). */
+#define MK_ALPHABET_NT2 0 /* A C G T -> 2-bit codes 0..3 (ASCII order)            */
+#define MK_ALPHABET_AA5 1 /* 'A'..'Z' -> 5-bit codes 0..25 (ASCII order)          */
+#define MK_ALPHABET_RAW 2 /* no packing: every window by reference (any k, any text) */
+
+typedef struct mk_ctx mk_ctx;
+
+/* Counters of one context, cumulative since mk_create / mk_reset_stats. */
+typedef struct mk_stats_t {
+  uint64_t raw_bytes;      /* FASTA bytes fed                                               */
+  uint64_t symbols;        /* sequence characters kept by the parser (the "bases")          */
+  uint64_t windows;        /* length-k windows counted (all paths)                          */
+  uint64_t exotic_windows; /* of those, windows counted by the by-reference path            */
+  uint64_t chunks;         /* chunks ended                                                  */
+  uint64_t survivors;      /* chunk-table entries that passed their chunk's min_count       */
+  uint64_t rows;           /* distinct k-mers now in the running (merged) table             */
+  uint64_t table_slots;    /* slots (or dense bins) of the chunk table of the last chunk    */
+  int32_t mode;            /* 0 dense-LDS, 1 hash64, 2 hash128, 3 by-reference only          */
+  int32_t profiled;        /* 1 when per-kernel HIP-event timing is on (mk_set_profiling)   */
+  /* HIP-event time per kernel family, milliseconds, and launches (only when profiled) */
+  double ms_parse, ms_pack, ms_count, ms_exotic, ms_filter, ms_export;
+  uint64_t n_parse, n_pack, n_count, n_exotic, n_filter, n_export;
+} mk_stats_t;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* One context per GPU and per (alphabet, k).  Replaces the per-task state of
+ * countKmers/find_kmers (bin/mercat2.py:112-114). */
+int mk_create(int device, int alphabet, int k, mk_ctx** out);
+void mk_destroy(mk_ctx* ctx);
+const char* mk_last_error(const mk_ctx* ctx);
+/* Forget the running (merged) table: start the next sample (run_mercat2's `kmers = dict()`,
+ * bin/mercat2.py:117). */
+int mk_reset(mk_ctx* ctx);
+
+/* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */
+int mk_chunk_begin(mk_ctx* ctx);
+/* Append raw FASTA bytes (host memory) of the current chunk; may be called repeatedly, the
+ * pieces are concatenated.  The buffer may be reused on return. */
+int mk_chunk_feed(mk_ctx* ctx, const uint8_t* text, size_t n);
+/* Same, from device memory of this context's GPU (used when the text is already in HBM). */
+int mk_chunk_feed_device(mk_ctx* ctx, const uint8_t* d_text, size_t n);
+/* Parse + pack + count the chunk, keep entries with count >= min_count
+ * (lib/mercat2_kmers.py:73-76) and add them into the running table
+ * (the dict sum of bin/mercat2.py:121-127). */
+int mk_chunk_end(mk_ctx* ctx, uint64_t min_count);
+/* Count a chunk in place from device memory without the staging copy (begin+feed+end).
+ * d_text must stay valid until the call returns. */
+int mk_count_device(mk_ctx* ctx, const uint8_t* d_text, size_t n, uint64_t min_count);
+
+/* ---- result of the sample: sorted(kmers.items()) (bin/mercat2.py:130-133) --------------- */
+int mk_export_size(mk_ctx* ctx, size_t* rows);
+/* kmers: rows*k ASCII bytes (no terminators), counts: rows values; both caller-allocated.
+ * Rows are in Python sorted(str) order == byte-wise order. */
+int mk_export(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t rows_cap);
+/* Writes "k-mer\t{basename}_Count\n" + rows; writes NO file and sets *rows = 0 when the
+ * table is empty (bin/mercat2.py:128-137). */
+int mk_write_tsv(mk_ctx* ctx, const char* path, const char* basename, size_t* rows);
+
+/* ---- multi-GPU merge plumbing (replaces ray.get + dict sum across workers) -------------- */
+/* Packed-key view of the running table for exchange over RCCL: *rows entries sorted by key
+ * into caller-provided DEVICE buffers (words_per_key = 1 for hash64/dense, 2 for hash128).
+ * By-reference (exotic) rows are exchanged through mk_export_exotic / mk_import_exotic. */
+int mk_export_pairs_device(mk_ctx* ctx, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows);
+/* insert-add (key,count) pairs from DEVICE buffers into the running table. */
+int mk_import_pairs_device(mk_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
+int mk_export_exotic(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t cap, size_t* rows);
+int mk_import_exotic(mk_ctx* ctx, const uint8_t* kmers, const uint64_t* counts, size_t rows);
+int mk_words_per_key(const mk_ctx* ctx);
+
+/* ---- statistics / profiling ----------------------------------------------------------- */
+int mk_set_profiling(mk_ctx* ctx, int on);
+int mk_get_stats(mk_ctx* ctx, mk_stats_t* out);
+int mk_reset_stats(mk_ctx* ctx);
+
+/* ---- host helpers (no GPU needed) ------------------------------------------------------- */
+/* Virtual Chunker (lib/mercat2_Chunker.py:39-59): byte offsets into `text` (decompressed file
+ * bytes) at which the reference would start chunk 1, 2, ...: a line that contains '>' starts
+ * a new chunk once the newline-normalised bytes written to the current chunk are >=
+ * chunksize.  cuts[0..*ncuts) ascending; chunk i is [cuts[i-1], cuts[i]) with cuts[-1] = 0
+ * and cuts[ncuts] = n.  Returns MK_ERR_RANGE (and the needed size in *ncuts) if cap is short. */
+int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, uint64_t* cuts, size_t cap, size_t* ncuts);
+/* Deterministic synthetic reads: genome of `genome_len` iid ACGT from
+ * splitmix64(genome_seed); `reads` reads of `read_len` from uniform starts, reverse-complemented
+ * on a coin flip, per-base substitution with probability sub_ppm/1e6, all from
+ * splitmix64(read_seed); records ">r{i}\n{seq}\n" with i starting at first_index.
+ * Writes at most cap bytes to out (host) and the size to *written (call with out = NULL to size). */
+int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_t reads, uint32_t read_len,
+                   uint64_t read_seed, uint32_t sub_ppm, uint64_t first_index, uint8_t* out, size_t cap,
+                   size_t* written);
+const char* mk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERCAT_HIP_H */

@@ -1,0 +1,675 @@
+// mk_api.hip -- the C ABI (include/mercat_hip.h): context, chunk pipeline, export.
+//
+// Chunk pipeline == one reference find_kmers call (lib/mercat2_kmers.py:32-78):
+//   raw bytes -> parse -> [pack] -> count (dense | hash64 | by-reference) -> keep count >= min_count
+//   -> add into the running table (the dict sum of run_mercat2, bin/mercat2.py:121-127).
+// Export == sorted(kmers.items()) + the TSV print loop (bin/mercat2.py:128-137).
+#include "mk_common.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+typedef unsigned long long u64;
+
+static thread_local std::string g_err;  // errors that have no context to live in
+
+static size_t pow2_at_least(size_t v) {
+  size_t p = 1024;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// ------------------------------------------------------------------------------ buffers
+int mk_buf_reserve(mk_ctx* c, MkDevBuf& b, size_t bytes, bool keep) {
+  if (bytes <= b.cap) return MK_OK;
+  size_t want = bytes;
+  if (keep && b.cap) want = std::max(bytes, b.cap + b.cap / 2);
+  want = (want + 255) & ~(size_t)255;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    c->err = "hipMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e);
+    return MK_ERR_NOMEM;
+  }
+  if (b.p) {
+    if (keep) {
+      e = hipMemcpyAsync(p, b.p, b.cap, hipMemcpyDeviceToDevice, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) {
+        (void)hipFree(p);
+        c->err = std::string("hipMemcpy (grow): ") + hipGetErrorString(e);
+        return MK_ERR_HIP;
+      }
+    } else {
+      (void)hipStreamSynchronize(c->stream);
+    }
+    (void)hipFree(b.p);
+  }
+  b.p = p;
+  b.cap = want;
+  return MK_OK;
+}
+
+static void buf_free(MkDevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// ---------------------------------------------------------------------------- profiling
+static hipEvent_t get_event(mk_ctx* c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void mk_prof_begin(mk_ctx* c, int id) {
+  if (!c->profile) return;
+  MkEventPair p{get_event(c), get_event(c), id};
+  (void)hipEventRecord(p.a, c->stream);
+  c->events.push_back(p);
+}
+
+void mk_prof_end(mk_ctx* c) {
+  if (!c->profile || c->events.empty()) return;
+  (void)hipEventRecord(c->events.back().b, c->stream);
+}
+
+static void prof_collect(mk_ctx* c) {
+  if (c->events.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  double* ms[MK_K_NUM] = {&c->st.ms_parse, &c->st.ms_pack, &c->st.ms_count, &c->st.ms_exotic, &c->st.ms_filter, &c->st.ms_export};
+  uint64_t* nn[MK_K_NUM] = {&c->st.n_parse, &c->st.n_pack, &c->st.n_count, &c->st.n_exotic, &c->st.n_filter, &c->st.n_export};
+  for (auto& p : c->events) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
+      *ms[p.id] += t;
+      *nn[p.id] += 1;
+    }
+    c->event_pool.push_back(p.a);
+    c->event_pool.push_back(p.b);
+  }
+  c->events.clear();
+}
+
+// ----------------------------------------------------------------------------- lifetime
+extern "C" const char* mk_version(void) { return "mercat_hip 0.1 (gfx950)"; }
+
+extern "C" const char* mk_last_error(const mk_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+extern "C" int mk_words_per_key(const mk_ctx* c) { return c ? 1 : 0; }
+
+static int pull_info(mk_ctx* c) {
+  MK_HIP(hipMemcpyAsync(c->h_info, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
+  if (!out) { g_err = "mk_create: out is NULL"; return MK_ERR_ARG; }
+  *out = nullptr;
+  if (k < 1 || k > (1 << 20)) { g_err = "mk_create: k must be in [1, 2^20]"; return MK_ERR_ARG; }
+  if (alphabet != MK_ALPHABET_NT2 && alphabet != MK_ALPHABET_AA5 && alphabet != MK_ALPHABET_RAW) {
+    g_err = "mk_create: unknown alphabet";
+    return MK_ERR_ARG;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_err = std::string("mk_create: no HIP device (") + (e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+            "); this engine has no CPU fallback";
+    return MK_ERR_HIP;
+  }
+  if (device < 0 || device >= ndev) { g_err = "mk_create: device index out of range"; return MK_ERR_ARG; }
+  mk_ctx* c = new (std::nothrow) mk_ctx();
+  if (!c) { g_err = "mk_create: out of host memory"; return MK_ERR_NOMEM; }
+  c->device = device;
+  c->alphabet = alphabet;
+  c->k = k;
+  c->bits = alphabet == MK_ALPHABET_NT2 ? 2 : (alphabet == MK_ALPHABET_AA5 ? 5 : 0);
+  c->syms_per_word = alphabet == MK_ALPHABET_NT2 ? 32 : 12;
+  const long kb = (long)k * c->bits;
+  c->mode = (c->bits == 0) ? MK_MODE_BYREF : (kb <= 15 ? MK_MODE_DENSE : (kb <= 64 ? MK_MODE_HASH64 : MK_MODE_BYREF));
+  c->st.mode = c->mode;
+  int rc = MK_OK;
+  auto fail = [&](int code, const std::string& msg) {
+    g_err = msg;
+    mk_destroy(c);
+    return code;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail(MK_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
+    return fail(MK_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+  if ((e = hipHostMalloc((void**)&c->h_info, sizeof(MkChunkInfo), hipHostMallocDefault)) != hipSuccess)
+    return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  if ((rc = mk_buf_reserve(c, c->info, sizeof(MkChunkInfo) + 64)) != MK_OK) return fail(rc, c->err);
+  if (c->mode == MK_MODE_DENSE) {
+    const size_t bytes = ((size_t)1 << kb) * sizeof(u64);
+    if ((rc = mk_buf_reserve(c, c->ctab, bytes)) != MK_OK) return fail(rc, c->err);
+    if ((rc = mk_buf_reserve(c, c->run, bytes)) != MK_OK) return fail(rc, c->err);
+    (void)hipMemsetAsync(c->ctab.p, 0, bytes, c->stream);
+    (void)hipMemsetAsync(c->run.p, 0, bytes, c->stream);
+    c->ctab_slots = c->run_slots = (size_t)1 << kb;
+  }
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess)
+    return fail(MK_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+  *out = c;
+  return MK_OK;
+}
+
+extern "C" void mk_destroy(mk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto& e : c->event_pool) (void)hipEventDestroy(e);
+  MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
+                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp};
+  for (auto* b : all) buf_free(*b);
+  if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int mk_reset(mk_ctx* c) {
+  if (!c) return MK_ERR_ARG;
+  MK_HIP(hipSetDevice(c->device));
+  if (c->mode == MK_MODE_DENSE) {
+    MK_HIP(hipMemsetAsync(c->run.p, 0, c->run_slots * sizeof(u64), c->stream));
+  } else if (c->run_slots) {
+    int rc = mk_launch_clear_slots(c, (MkSlot*)c->run.p, c->run_slots);
+    if (rc) return rc;
+  }
+  if (c->run_ref_slots) {
+    int rc = mk_launch_clear_slots(c, (MkSlot*)c->run_ref.p, c->run_ref_slots);
+    if (rc) return rc;
+  }
+  c->run_rows = 0;
+  c->run_ref_rows = 0;
+  c->run_side = 0;
+  c->in_chunk = false;
+  c->raw_len = 0;
+  MK_HIP(hipStreamSynchronize(c->stream));
+  return MK_OK;
+}
+
+// ----------------------------------------------------------------------------- chunk feed
+extern "C" int mk_chunk_begin(mk_ctx* c) {
+  if (!c) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_chunk_begin: a chunk is already open"; return MK_ERR_STATE; }
+  c->in_chunk = true;
+  c->raw_len = 0;
+  return MK_OK;
+}
+
+static int feed(mk_ctx* c, const uint8_t* p, size_t n, hipMemcpyKind kind) {
+  if (!c) return MK_ERR_ARG;
+  if (!c->in_chunk) { c->err = "mk_chunk_feed: no open chunk (call mk_chunk_begin)"; return MK_ERR_STATE; }
+  if (n == 0) return MK_OK;
+  if (!p) { c->err = "mk_chunk_feed: text is NULL"; return MK_ERR_ARG; }
+  MK_HIP(hipSetDevice(c->device));
+  int rc = mk_buf_reserve(c, c->raw, c->raw_len + n + 64, true);
+  if (rc) return rc;
+  MK_HIP(hipMemcpyAsync((uint8_t*)c->raw.p + c->raw_len, p, n, kind, c->stream));
+  if (kind == hipMemcpyHostToDevice) MK_HIP(hipStreamSynchronize(c->stream));  // caller may reuse its buffer
+  c->raw_len += n;
+  return MK_OK;
+}
+
+extern "C" int mk_chunk_feed(mk_ctx* c, const uint8_t* text, size_t n) { return feed(c, text, n, hipMemcpyHostToDevice); }
+extern "C" int mk_chunk_feed_device(mk_ctx* c, const uint8_t* d_text, size_t n) {
+  return feed(c, d_text, n, hipMemcpyDeviceToDevice);
+}
+
+// ------------------------------------------------------------------------ running tables
+static int grow_run64(mk_ctx* c, size_t need_rows) {
+  if (2 * need_rows <= c->run_slots) return MK_OK;
+  const size_t slots = pow2_at_least(4 * need_rows);
+  MkDevBuf nb;
+  int rc = mk_buf_reserve(c, nb, slots * sizeof(MkSlot));
+  if (rc) return rc;
+  if ((rc = mk_launch_clear_slots(c, (MkSlot*)nb.p, slots)) != MK_OK) return rc;
+  if (c->run_slots && (rc = mk_launch_rehash64(c, (const MkSlot*)c->run.p, c->run_slots, (MkSlot*)nb.p, slots)) != MK_OK) return rc;
+  MK_HIP(hipStreamSynchronize(c->stream));
+  buf_free(c->run);
+  c->run = nb;
+  c->run_slots = slots;
+  return MK_OK;
+}
+
+static int grow_run_ref(mk_ctx* c, size_t need_rows) {
+  int rc;
+  if (need_rows > c->arena_rows_cap) {
+    const size_t rows = std::max(need_rows, c->arena_rows_cap * 2);
+    if ((rc = mk_buf_reserve(c, c->arena, rows * (size_t)c->k + 64, true)) != MK_OK) return rc;
+    c->arena_rows_cap = rows;
+  }
+  if (2 * need_rows <= c->run_ref_slots) return MK_OK;
+  const size_t slots = pow2_at_least(4 * need_rows);
+  MkDevBuf nb;
+  if ((rc = mk_buf_reserve(c, nb, slots * sizeof(MkSlot))) != MK_OK) return rc;
+  if ((rc = mk_launch_clear_slots(c, (MkSlot*)nb.p, slots)) != MK_OK) return rc;
+  if (c->run_ref_slots &&
+      (rc = mk_launch_rehash_ref(c, (const MkSlot*)c->run_ref.p, c->run_ref_slots, (MkSlot*)nb.p, slots)) != MK_OK)
+    return rc;
+  MK_HIP(hipStreamSynchronize(c->stream));
+  buf_free(c->run_ref);
+  c->run_ref = nb;
+  c->run_ref_slots = slots;
+  return MK_OK;
+}
+
+// --------------------------------------------------------------------------- the pipeline
+static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
+  int rc;
+  MK_HIP(hipSetDevice(c->device));
+  MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if ((rc = mk_buf_reserve(c, c->seq, n + 256)) != MK_OK) return rc;
+  if ((rc = mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
+  const bool packed = c->mode != MK_MODE_BYREF;
+  if (packed) {
+    const size_t bad_words = n / 64 + 4;
+    const size_t code_words = c->alphabet == MK_ALPHABET_NT2 ? 2 * bad_words : (bad_words * 64 + 11) / 12;
+    if ((rc = mk_buf_reserve(c, c->bad, (bad_words + 2) * 8)) != MK_OK) return rc;
+    if ((rc = mk_buf_reserve(c, c->codes, (code_words + 8) * 8)) != MK_OK) return rc;
+    if ((rc = mk_launch_pack(c, n)) != MK_OK) return rc;
+  }
+  if ((rc = pull_info(c)) != MK_OK) return rc;
+  if (c->h_info->non_ascii) {
+    c->err = "input holds " + std::to_string(c->h_info->non_ascii) +
+             " byte(s) >= 0x80 (non-ASCII text is not supported; the chunk was not counted)";
+    return MK_ERR_NON_ASCII;
+  }
+  const size_t seq_len = (size_t)c->h_info->seq_len;
+  const u64 bad_symbols = c->h_info->bad_symbols;
+
+  // chunk tables
+  c->rtab_chunk_slots = 0;
+  if (c->mode == MK_MODE_HASH64) {
+    c->ctab_slots = pow2_at_least(2 * seq_len);
+    if ((rc = mk_buf_reserve(c, c->ctab, c->ctab_slots * sizeof(MkSlot))) != MK_OK) return rc;
+    if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
+  }
+  if (c->mode == MK_MODE_BYREF) {
+    c->rtab_chunk_slots = pow2_at_least(2 * seq_len);
+  } else if (bad_symbols) {
+    const u64 bound = std::min<u64>((u64)seq_len, bad_symbols * (u64)c->k);
+    c->rtab_chunk_slots = pow2_at_least(2 * (size_t)bound);
+  }
+  if (c->rtab_chunk_slots) {
+    if ((rc = mk_buf_reserve(c, c->rtab_chunk, c->rtab_chunk_slots * sizeof(MkSlot))) != MK_OK) return rc;
+    if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots)) != MK_OK) return rc;
+  }
+  c->st.table_slots = c->mode == MK_MODE_BYREF ? c->rtab_chunk_slots : c->ctab_slots;
+
+  // count
+  if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
+  else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
+  if (rc) return rc;
+  if (c->rtab_chunk_slots && (rc = mk_launch_count_byref(c, seq_len, packed)) != MK_OK) return rc;
+
+  // filter (per chunk!) + merge
+  if ((rc = mk_launch_count_survivors(c, min_count)) != MK_OK) return rc;
+  if ((rc = pull_info(c)) != MK_OK) return rc;
+  if (c->mode == MK_MODE_HASH64 && c->h_info->survivors)
+    if ((rc = grow_run64(c, c->run_rows + (size_t)c->h_info->survivors)) != MK_OK) return rc;
+  if (c->h_info->survivors_ref)
+    if ((rc = grow_run_ref(c, c->run_ref_rows + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
+  if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;
+  if ((rc = pull_info(c)) != MK_OK) return rc;
+  c->run_rows += (size_t)c->h_info->new_rows;
+  c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
+  if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
+
+  c->st.raw_bytes += n;
+  c->st.symbols += c->h_info->symbols;
+  c->st.windows += c->h_info->windows + c->h_info->exotic;
+  c->st.exotic_windows += c->h_info->exotic;
+  c->st.chunks += 1;
+  c->st.survivors += c->h_info->survivors + c->h_info->survivors_ref +
+                     ((c->h_info->side && c->h_info->side >= min_count) ? 1 : 0);
+  return MK_OK;
+}
+
+extern "C" int mk_chunk_end(mk_ctx* c, uint64_t min_count) {
+  if (!c) return MK_ERR_ARG;
+  if (!c->in_chunk) { c->err = "mk_chunk_end: no open chunk"; return MK_ERR_STATE; }
+  c->in_chunk = false;
+  int rc = process_chunk(c, (const uint8_t*)c->raw.p, c->raw_len, min_count);
+  c->raw_len = 0;
+  return rc;
+}
+
+extern "C" int mk_count_device(mk_ctx* c, const uint8_t* d_text, size_t n, uint64_t min_count) {
+  if (!c) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_count_device: a chunk is open"; return MK_ERR_STATE; }
+  if (n && !d_text) { c->err = "mk_count_device: d_text is NULL"; return MK_ERR_ARG; }
+  if (((uintptr_t)d_text & 15) == 0) return process_chunk(c, d_text, n, min_count);
+  int rc = mk_chunk_begin(c);
+  if (!rc) rc = mk_chunk_feed_device(c, d_text, n);
+  if (rc) { c->in_chunk = false; return rc; }
+  return mk_chunk_end(c, min_count);
+}
+
+// --------------------------------------------------------------------------------- export
+struct ExportView {
+  std::vector<u64> pkeys, pcnts;     // packed rows, sorted by key
+  std::vector<uint8_t> rstr;         // by-reference rows: k bytes each, arena order
+  std::vector<u64> rcnt;             // counts in arena order
+  std::vector<u64> rorder;           // arena rows sorted by string
+};
+
+static int gather_packed(mk_ctx* c, ExportView& v, u64* d_keys_out, u64* d_cnts_out, size_t cap, size_t* rows_out,
+                         bool to_host) {
+  int rc;
+  size_t rows = 0;
+  if (c->mode == MK_MODE_DENSE) {
+    const size_t nbins = c->run_slots;
+    std::vector<u64> bins(nbins);
+    MK_HIP(hipMemcpyAsync(bins.data(), c->run.p, nbins * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < nbins; ++i)
+      if (bins[i]) { v.pkeys.push_back(i); v.pcnts.push_back(bins[i]); }
+    rows = v.pkeys.size();
+    if (!to_host) {
+      if (rows > cap) { c->err = "export: device buffers too small"; return MK_ERR_RANGE; }
+      if (rows) {
+        MK_HIP(hipMemcpyAsync(d_keys_out, v.pkeys.data(), rows * 8, hipMemcpyHostToDevice, c->stream));
+        MK_HIP(hipMemcpyAsync(d_cnts_out, v.pcnts.data(), rows * 8, hipMemcpyHostToDevice, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
+      }
+    }
+  } else if (c->mode == MK_MODE_HASH64) {
+    rows = c->run_rows;
+    const size_t side = c->run_side ? 1 : 0;
+    if (!to_host && rows + side > cap) { c->err = "export: device buffers too small"; return MK_ERR_RANGE; }
+    if (rows) {
+      mk_prof_begin(c, MK_K_EXPORT);
+      if ((rc = mk_buf_reserve(c, c->ex_keys, rows * 8 + 64)) != MK_OK) return rc;
+      if ((rc = mk_buf_reserve(c, c->ex_cnts, rows * 8 + 64)) != MK_OK) return rc;
+      u64* d_cursor = (u64*)((char*)c->info.p + sizeof(MkChunkInfo));
+      MK_HIP(hipMemsetAsync(d_cursor, 0, 8, c->stream));
+      if ((rc = mk_launch_compact(c, (const MkSlot*)c->run.p, c->run_slots, (uint64_t*)c->ex_keys.p,
+                                  (uint64_t*)c->ex_cnts.p, rows, (uint64_t*)d_cursor)) != MK_OK) return rc;
+      u64* ok = d_keys_out;
+      u64* oc = d_cnts_out;
+      if (to_host) {
+        if ((rc = mk_buf_reserve(c, c->ex_keys2, rows * 8 + 64)) != MK_OK) return rc;
+        if ((rc = mk_buf_reserve(c, c->ex_cnts2, rows * 8 + 64)) != MK_OK) return rc;
+        ok = (u64*)c->ex_keys2.p;
+        oc = (u64*)c->ex_cnts2.p;
+      }
+      if ((rc = mk_sort_pairs(c, (const uint64_t*)c->ex_keys.p, (const uint64_t*)c->ex_cnts.p, (uint64_t*)ok,
+                              (uint64_t*)oc, rows, c->bits * c->k)) != MK_OK) return rc;
+      mk_prof_end(c);
+      if (to_host) {
+        v.pkeys.resize(rows);
+        v.pcnts.resize(rows);
+        MK_HIP(hipMemcpyAsync(v.pkeys.data(), ok, rows * 8, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipMemcpyAsync(v.pcnts.data(), oc, rows * 8, hipMemcpyDeviceToHost, c->stream));
+      }
+      u64 got = 0;
+      MK_HIP(hipMemcpyAsync(&got, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+      MK_HIP(hipStreamSynchronize(c->stream));
+      if (got != rows) {
+        c->err = "export: table holds " + std::to_string(got) + " rows, expected " + std::to_string(rows);
+        return MK_ERR_STATE;
+      }
+    }
+    if (side) {  // the all-ones key (32 x 'T'): the largest key, so it goes last
+      if (to_host) { v.pkeys.push_back(MK_EMPTY); v.pcnts.push_back(c->run_side); }
+      else {
+        u64 kk = MK_EMPTY, cc = c->run_side;
+        MK_HIP(hipMemcpyAsync(d_keys_out + rows, &kk, 8, hipMemcpyHostToDevice, c->stream));
+        MK_HIP(hipMemcpyAsync(d_cnts_out + rows, &cc, 8, hipMemcpyHostToDevice, c->stream));
+        MK_HIP(hipStreamSynchronize(c->stream));
+      }
+      rows += 1;
+    }
+  }
+  if (rows_out) *rows_out = rows;
+  return MK_OK;
+}
+
+static int gather_ref(mk_ctx* c, ExportView& v, bool sorted) {
+  const size_t rows = c->run_ref_rows;
+  if (!rows) return MK_OK;
+  int rc;
+  const size_t k = (size_t)c->k;
+  if ((rc = mk_buf_reserve(c, c->ex_keys, rows * 8 + 64)) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->ex_cnts, rows * 8 + 64)) != MK_OK) return rc;
+  u64* d_cursor = (u64*)((char*)c->info.p + sizeof(MkChunkInfo));
+  MK_HIP(hipMemsetAsync(d_cursor, 0, 8, c->stream));
+  if ((rc = mk_launch_compact(c, (const MkSlot*)c->run_ref.p, c->run_ref_slots, (uint64_t*)c->ex_keys.p,
+                              (uint64_t*)c->ex_cnts.p, rows, (uint64_t*)d_cursor)) != MK_OK) return rc;
+  std::vector<u64> keys(rows), cnts(rows);
+  v.rstr.resize(rows * k);
+  MK_HIP(hipMemcpyAsync(keys.data(), c->ex_keys.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipMemcpyAsync(cnts.data(), c->ex_cnts.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipMemcpyAsync(v.rstr.data(), c->arena.p, rows * k, hipMemcpyDeviceToHost, c->stream));
+  u64 got = 0;
+  MK_HIP(hipMemcpyAsync(&got, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  if (got != rows) {
+    c->err = "export: by-reference table holds " + std::to_string(got) + " rows, expected " + std::to_string(rows);
+    return MK_ERR_STATE;
+  }
+  v.rcnt.assign(rows, 0);
+  for (size_t i = 0; i < rows; ++i) {
+    const u64 row = keys[i] & ((1ull << 40) - 1);
+    if (row >= rows) { c->err = "export: corrupt by-reference row index"; return MK_ERR_STATE; }
+    v.rcnt[row] = cnts[i];
+  }
+  v.rorder.resize(rows);
+  for (size_t i = 0; i < rows; ++i) v.rorder[i] = i;
+  if (sorted) {
+    const uint8_t* base = v.rstr.data();
+    std::sort(v.rorder.begin(), v.rorder.end(),
+              [base, k](u64 a, u64 b) { return memcmp(base + a * k, base + b * k, k) < 0; });
+  }
+  return MK_OK;
+}
+
+static inline void decode_key(const mk_ctx* c, u64 key, uint8_t* out) {
+  const int k = c->k;
+  if (c->alphabet == MK_ALPHABET_NT2) {
+    for (int j = k - 1; j >= 0; --j) { out[j] = "ACGT"[key & 3]; key >>= 2; }
+  } else {
+    for (int j = k - 1; j >= 0; --j) { out[j] = (uint8_t)('A' + (key & 31)); key >>= 5; }
+  }
+}
+
+// Visit every row in sorted(str) order: a 2-way merge of the packed rows (decoded on the fly)
+// and the by-reference rows.
+template <class F>
+static void merged_rows(const mk_ctx* c, const ExportView& v, F&& f) {
+  const size_t k = (size_t)c->k, np = v.pkeys.size(), nr = v.rorder.size();
+  std::vector<uint8_t> buf(k ? k : 1);
+  size_t i = 0, j = 0;
+  bool have = false;
+  while (i < np || j < nr) {
+    if (i < np && !have) { decode_key(c, v.pkeys[i], buf.data()); have = true; }
+    bool take_packed;
+    if (i >= np) take_packed = false;
+    else if (j >= nr) take_packed = true;
+    else take_packed = memcmp(buf.data(), v.rstr.data() + v.rorder[j] * k, k) < 0;
+    if (take_packed) { f(buf.data(), v.pcnts[i]); ++i; have = false; }
+    else { f(v.rstr.data() + v.rorder[j] * k, v.rcnt[v.rorder[j]]); ++j; }
+  }
+}
+
+static int build_view(mk_ctx* c, ExportView& v) {
+  MK_HIP(hipSetDevice(c->device));
+  int rc = gather_packed(c, v, nullptr, nullptr, 0, nullptr, true);
+  if (rc) return rc;
+  return gather_ref(c, v, true);
+}
+
+extern "C" int mk_export_size(mk_ctx* c, size_t* rows) {
+  if (!c || !rows) return MK_ERR_ARG;
+  if (c->mode == MK_MODE_DENSE) {
+    ExportView v;
+    MK_HIP(hipSetDevice(c->device));
+    int rc = gather_packed(c, v, nullptr, nullptr, 0, nullptr, true);
+    if (rc) return rc;
+    *rows = v.pkeys.size() + c->run_ref_rows;
+  } else {
+    *rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows;
+  }
+  c->st.rows = *rows;
+  return MK_OK;
+}
+
+extern "C" int mk_export(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t rows_cap) {
+  if (!c) return MK_ERR_ARG;
+  ExportView v;
+  int rc = build_view(c, v);
+  if (rc) return rc;
+  const size_t rows = v.pkeys.size() + v.rorder.size();
+  if (rows > rows_cap) { c->err = "mk_export: rows_cap too small"; return MK_ERR_RANGE; }
+  if (rows && (!kmers || !counts)) { c->err = "mk_export: NULL output"; return MK_ERR_ARG; }
+  const size_t k = (size_t)c->k;
+  size_t at = 0;
+  merged_rows(c, v, [&](const uint8_t* s, u64 n) {
+    memcpy(kmers + at * k, s, k);
+    counts[at] = n;
+    ++at;
+  });
+  return MK_OK;
+}
+
+extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, size_t* rows_out) {
+  if (!c || !path || !basename) return MK_ERR_ARG;
+  ExportView v;
+  int rc = build_view(c, v);
+  if (rc) return rc;
+  const size_t rows = v.pkeys.size() + v.rorder.size();
+  if (rows_out) *rows_out = rows;
+  if (!rows) return MK_OK;  // bin/mercat2.py:135-137: no file when nothing survives
+  FILE* f = fopen(path, "wb");
+  if (!f) { c->err = std::string("mk_write_tsv: cannot open ") + path; return MK_ERR_IO; }
+  std::vector<char> out;
+  out.reserve(1 << 22);
+  const size_t k = (size_t)c->k;
+  auto flush = [&]() {
+    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+  };
+  const std::string head = std::string("k-mer\t") + basename + "_Count\n";
+  out.insert(out.end(), head.begin(), head.end());
+  merged_rows(c, v, [&](const uint8_t* s, u64 n) {
+    out.insert(out.end(), (const char*)s, (const char*)s + k);
+    out.push_back('\t');
+    char num[24];
+    int len = 0;
+    do { num[len++] = (char)('0' + n % 10); n /= 10; } while (n);
+    while (len) out.push_back(num[--len]);
+    out.push_back('\n');
+    if (out.size() > (1u << 22) - 4096 - k) flush();
+  });
+  flush();
+  const bool bad = ferror(f) != 0;
+  if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_tsv: write failed: ") + path; return MK_ERR_IO; }
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------- multi-GPU plumbing
+extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows) {
+  if (!c || !rows) return MK_ERR_ARG;
+  if (c->mode == MK_MODE_BYREF) { *rows = 0; return MK_OK; }
+  MK_HIP(hipSetDevice(c->device));
+  ExportView v;
+  return gather_packed(c, v, (u64*)d_keys, (u64*)d_counts, cap, rows, false);
+}
+
+extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
+  if (!c) return MK_ERR_ARG;
+  if (!rows) return MK_OK;
+  if (c->mode == MK_MODE_BYREF) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
+  MK_HIP(hipSetDevice(c->device));
+  int rc;
+  MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if (c->mode == MK_MODE_HASH64) {
+    // the all-ones key travels as an ordinary pair; peel it off on the host side of the call
+    std::vector<u64> last(2);
+    MK_HIP(hipMemcpyAsync(&last[0], d_keys + rows - 1, 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(&last[1], d_counts + rows - 1, 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    if (last[0] == MK_EMPTY) { c->run_side += last[1]; rows -= 1; }
+    if ((rc = grow_run64(c, c->run_rows + rows)) != MK_OK) return rc;
+  }
+  if ((rc = mk_launch_import_pairs(c, d_keys, d_counts, rows)) != MK_OK) return rc;
+  if ((rc = pull_info(c)) != MK_OK) return rc;
+  c->run_rows += (size_t)c->h_info->new_rows;
+  return MK_OK;
+}
+
+extern "C" int mk_export_exotic(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t cap, size_t* rows) {
+  if (!c || !rows) return MK_ERR_ARG;
+  MK_HIP(hipSetDevice(c->device));
+  ExportView v;
+  int rc = gather_ref(c, v, true);
+  if (rc) return rc;
+  *rows = v.rorder.size();
+  if (!kmers && !counts) return MK_OK;  // size query
+  if (*rows > cap) { c->err = "mk_export_exotic: cap too small"; return MK_ERR_RANGE; }
+  const size_t k = (size_t)c->k;
+  for (size_t i = 0; i < v.rorder.size(); ++i) {
+    memcpy(kmers + i * k, v.rstr.data() + v.rorder[i] * k, k);
+    counts[i] = v.rcnt[v.rorder[i]];
+  }
+  return MK_OK;
+}
+
+extern "C" int mk_import_exotic(mk_ctx* c, const uint8_t* kmers, const uint64_t* counts, size_t rows) {
+  if (!c) return MK_ERR_ARG;
+  if (!rows) return MK_OK;
+  if (!kmers || !counts) return MK_ERR_ARG;
+  MK_HIP(hipSetDevice(c->device));
+  int rc;
+  const size_t k = (size_t)c->k;
+  if ((rc = mk_buf_reserve(c, c->ex_keys2, rows * k + 64)) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->ex_cnts2, rows * 8 + 64)) != MK_OK) return rc;
+  MK_HIP(hipMemcpyAsync(c->ex_keys2.p, kmers, rows * k, hipMemcpyHostToDevice, c->stream));
+  MK_HIP(hipMemcpyAsync(c->ex_cnts2.p, counts, rows * 8, hipMemcpyHostToDevice, c->stream));
+  MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if ((rc = grow_run_ref(c, c->run_ref_rows + rows)) != MK_OK) return rc;
+  if ((rc = mk_launch_import_ref(c, (const uint8_t*)c->ex_keys2.p, (const uint64_t*)c->ex_cnts2.p, rows)) != MK_OK) return rc;
+  if ((rc = pull_info(c)) != MK_OK) return rc;
+  c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
+  return MK_OK;
+}
+
+// ----------------------------------------------------------------------------------- stats
+extern "C" int mk_set_profiling(mk_ctx* c, int on) {
+  if (!c) return MK_ERR_ARG;
+  prof_collect(c);
+  c->profile = on != 0;
+  c->st.profiled = c->profile ? 1 : 0;
+  return MK_OK;
+}
+
+extern "C" int mk_get_stats(mk_ctx* c, mk_stats_t* out) {
+  if (!c || !out) return MK_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  prof_collect(c);
+  c->st.mode = c->mode;
+  if (c->mode != MK_MODE_DENSE) c->st.rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows;
+  *out = c->st;
+  return MK_OK;
+}
+
+extern "C" int mk_reset_stats(mk_ctx* c) {
+  if (!c) return MK_ERR_ARG;
+  prof_collect(c);
+  const int mode = c->st.mode, prof = c->st.profiled;
+  c->st = mk_stats_t{};
+  c->st.mode = mode;
+  c->st.profiled = prof;
+  return MK_OK;
+}

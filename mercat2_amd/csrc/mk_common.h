@@ -1,0 +1,165 @@
+// mk_common.h -- shared declarations of the MI355X k-mer engine (internal, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/mercat_hip.h"
+
+// ------------------------------------------------------------------------------------------
+// Device data layout (all in HBM, owned by the context)
+//
+//   raw      u8[n]            the chunk's FASTA bytes as fed
+//   seq      u8[<=n]          parsed stream: kept sequence characters, records separated by
+//                             one SEP byte ('\n' can never be a kept character)
+//   codes    u64[...]         packed symbols, MSB first: 32 x 2-bit (nt) or 12 x 5-bit (aa,
+//                             bits 63..4) per word
+//   bad      u64[...]         1 bit per symbol (LSB first): symbol outside the alphabet, a
+//                             separator, or beyond the end of seq
+//   table    Slot[2^m]        open-addressed, linear probing, 16-byte slots {key, count}
+//   table128 Slot128[2^m]     32-byte slots {hi, lo, count, pad} for 33..64-mers
+//   bins     u64[4^k | 32^k]  dense histogram (small k)
+// ------------------------------------------------------------------------------------------
+
+#define MK_SEP 0x0Au
+#define MK_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+struct __attribute__((aligned(16))) MkSlot {
+  unsigned long long key;
+  unsigned long long cnt;
+};
+
+struct __attribute__((aligned(32))) MkSlot128 {
+  unsigned long long hi;  // MK_EMPTY = free, MK_EMPTY-1 = being written
+  unsigned long long lo;
+  unsigned long long cnt;
+  unsigned long long pad;
+};
+
+// Device-side scalars of one chunk (one struct in HBM, read back once per chunk).
+struct MkChunkInfo {
+  unsigned long long seq_len;       // bytes in seq (symbols + separators)
+  unsigned long long symbols;       // kept sequence characters
+  unsigned long long non_ascii;     // bytes >= 0x80 seen in raw
+  unsigned long long bad_symbols;   // kept characters outside the alphabet
+  unsigned long long windows;       // windows counted by the packed/dense path
+  unsigned long long exotic;        // windows counted by the by-reference path
+  unsigned long long survivors;     // packed entries passing min_count (this chunk)
+  unsigned long long survivors_ref; // by-reference entries passing min_count
+  unsigned long long side;          // count of the one key that equals MK_EMPTY (all-T 32-mer)
+  unsigned long long new_rows;      // rows added to the running table by this chunk
+  unsigned long long new_rows_ref;
+  unsigned long long pad[5];
+};
+
+enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
+enum MkKernelId { MK_K_PARSE = 0, MK_K_PACK, MK_K_COUNT, MK_K_EXOTIC, MK_K_FILTER, MK_K_EXPORT, MK_K_NUM };
+
+// 64-bit finaliser (splitmix64 / murmur3 style): bijective, mixes every input bit into every
+// output bit -- used to pick the home slot of a packed key.
+__host__ __device__ static inline unsigned long long mk_mix64(unsigned long long x) {
+  x ^= x >> 30;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27;
+  x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return x;
+}
+
+#define MK_POLY_B 0x9E3779B97F4A7C15ull  // odd multiplier of the rolling polynomial hash
+
+struct MkDevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+// Simple growable device buffer helpers (implemented in mk_api.cpp)
+struct mk_ctx;
+int mk_buf_reserve(mk_ctx* c, MkDevBuf& b, size_t bytes, bool keep = false);
+
+struct MkEventPair {
+  hipEvent_t a, b;
+  int id;
+};
+
+struct mk_ctx {
+  int device = 0;
+  int alphabet = 0;
+  int k = 0;
+  int bits = 0;           // bits per symbol (2, 5, 0 for raw)
+  int syms_per_word = 0;  // 32, 12
+  int mode = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool in_chunk = false;
+  bool profile = false;
+
+  // chunk staging
+  MkDevBuf raw;
+  size_t raw_len = 0;
+  MkDevBuf seq, codes, bad;
+  MkDevBuf tile_maps;   // parse scratch
+  MkDevBuf info;        // MkChunkInfo on device
+  MkChunkInfo* h_info = nullptr;  // pinned host copy
+
+  // chunk tables
+  MkDevBuf ctab;        // MkSlot[] (hash64) / MkSlot128[] (hash128) / u64 bins (dense)
+  size_t ctab_slots = 0;
+  MkDevBuf rtab_chunk;  // by-reference chunk table MkSlot[] (key = tag|pos)
+  size_t rtab_chunk_slots = 0;
+
+  // running (merged) tables
+  MkDevBuf run;         // same layout as ctab (dense: u64 bins)
+  size_t run_slots = 0;
+  size_t run_rows = 0;
+  unsigned long long run_side = 0;  // count of the MK_EMPTY-valued key
+  MkDevBuf run_ref;     // by-reference running table MkSlot[] (key = tag|arena index)
+  size_t run_ref_slots = 0;
+  size_t run_ref_rows = 0;
+  MkDevBuf arena;       // k bytes per by-reference row
+  size_t arena_rows_cap = 0;
+
+  // export scratch
+  MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
+
+  // stats
+  mk_stats_t st{};
+  std::vector<MkEventPair> events;
+  std::vector<hipEvent_t> event_pool;
+};
+
+#define MK_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e__ = (call);                                                                 \
+    if (e__ != hipSuccess) {                                                                 \
+      c->err = std::string(#call) + ": " + hipGetErrorString(e__);                           \
+      return MK_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+// ---- kernel launchers (each in its own translation unit) ---------------------------------
+// parse: raw[n] -> seq, info (seq_len, symbols, non_ascii)
+int mk_launch_parse(mk_ctx* c, const uint8_t* d_raw, size_t n);
+// pack: seq -> codes, bad (+ info.bad_symbols)
+int mk_launch_pack(mk_ctx* c, size_t seq_cap);
+// counting
+int mk_launch_count_dense(mk_ctx* c, size_t seq_cap);
+int mk_launch_count_hash64(mk_ctx* c, size_t seq_cap);
+int mk_launch_count_byref(mk_ctx* c, size_t seq_cap, bool exotic_only);
+// tables
+int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
+int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);
+int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
+int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
+int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
+int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
+int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows);
+// export helpers
+int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys, uint64_t* d_counts, size_t cap,
+                      uint64_t* d_cursor);
+int mk_sort_pairs(mk_ctx* c, const uint64_t* keys_in, const uint64_t* vals_in, uint64_t* keys_out, uint64_t* vals_out,
+                  size_t n, int key_bits);
+
+void mk_prof_begin(mk_ctx* c, int id);
+void mk_prof_end(mk_ctx* c);

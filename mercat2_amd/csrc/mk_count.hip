@@ -1,0 +1,311 @@
+// mk_count.hip -- the counting kernels: every length-k window of every record, +1 in its bin.
+//
+// Replaces the reference's inner loop (lib/mercat2_kmers.py:56-60, 65-69)
+//     for i in range(len(seq)-k+1): kmerlist[seq[i:i+k]] += 1
+// with three GPU forms that together count *every* window exactly:
+//   dense   k*BITS <= 15: direct-index histogram, private to the workgroup in LDS
+//           (replicated per lane group when the bin count is small), one global add per
+//           non-zero bin per workgroup;
+//   hash64  k*BITS <= 64: packed key, open-addressed table of 16-byte {key,count} slots in
+//           HBM, linear probing, claim by atomicCAS, count by no-return atomicAdd;
+//   byref   any k, any character: the table stores the *position* of the first occurrence
+//           (plus a hash tag); equality is a k-byte compare in the parsed stream. It takes
+//           (a) every window when there is no packed form for (alphabet,k) and (b) in the
+//           packed modes exactly the windows that hold a character outside the alphabet, so
+//           the union is the reference's "any character" semantics.
+// A window is counted iff it lies inside one record (no separator) -- lib/mercat2_kmers.py:52-61.
+#include "mk_common.h"
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------------ packed windows
+// Key of the k symbols that start at symbol s (static) of `cur`, continuing into `nxt`.
+template <int BITS, int SPW>
+__device__ __forceinline__ u64 window_key(u64 cur, u64 nxt, int s, int k) {
+  u64 key = (cur << (BITS * s)) >> (64 - BITS * k);
+  const int over = s + k - SPW;  // symbols taken from the next word
+  if (over > 0) key |= nxt >> (64 - BITS * over);
+  return key;
+}
+
+__device__ __forceinline__ u64 bad_window(const u64* __restrict__ bad, size_t p0) {
+  const size_t bi = p0 >> 6;
+  const int bo = (int)(p0 & 63);
+  const u64 b0 = bad[bi];
+  if (bo == 0) return b0;
+  return (b0 >> bo) | (bad[bi + 1] << (64 - bo));
+}
+
+__device__ __forceinline__ void add_windows(MkChunkInfo* info, unsigned mine, bool exotic) {
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(exotic ? &info->exotic : &info->windows, (u64)mine);
+}
+
+// ------------------------------------------------------------------------------ hash64
+__device__ __forceinline__ void insert64(MkSlot* __restrict__ table, u64 mask, u64 key, u64 add) {
+  u64 slot = mk_mix64(key) & mask;
+  for (;;) {
+    u64 cur = table[slot].key;
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&table[slot].key, MK_EMPTY, key);
+      if (cur == MK_EMPTY) cur = key;
+    }
+    if (cur == key) {
+      atomicAdd(&table[slot].cnt, add);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+template <int BITS, int SPW, int WPT>
+__global__ __launch_bounds__(256) void mk_count_hash64_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                         MkChunkInfo* __restrict__ info, MkSlot* __restrict__ table,
+                                                         u64 mask, int k) {
+  constexpr int R = SPW * WPT;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t p0 = t * R;
+  unsigned mine = 0;
+  if (p0 < info->seq_len) {
+    u64 w[WPT + 1];
+#pragma unroll
+    for (int i = 0; i <= WPT; ++i) w[i] = codes[t * WPT + i];
+    const u64 badw = bad_window(bad, p0);
+    const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+    if ((badw & ((R + k - 1 >= 64) ? ~0ull : ((1ull << (R + k - 1)) - 1))) == 0) {
+      // fast path: no bad symbol anywhere in this thread's span
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+          u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+          if (key == MK_EMPTY) atomicAdd(&info->side, 1ull); else insert64(table, mask, key, 1);
+        }
+      }
+      mine = R;
+    } else {
+#pragma unroll
+      for (int i = 0; i < WPT; ++i) {
+#pragma unroll
+        for (int s = 0; s < SPW; ++s) {
+          if (((badw >> (i * SPW + s)) & kmask) == 0) {
+            u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+            if (key == MK_EMPTY) atomicAdd(&info->side, 1ull); else insert64(table, mask, key, 1);
+            ++mine;
+          }
+        }
+      }
+    }
+  }
+  add_windows(info, mine, false);
+}
+
+// ------------------------------------------------------------------------------- dense
+// LDS histogram hist[bin * copies + (lane & (copies-1))]: with few bins the copies put the
+// lanes of a wave on different banks/addresses; flushed with one atomicAdd per non-zero bin.
+template <int BITS, int SPW, int WPT>
+__global__ __launch_bounds__(256) void mk_count_dense_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                        MkChunkInfo* __restrict__ info, u64* __restrict__ bins,
+                                                        unsigned nbins, unsigned copies_log2, int k, size_t nthreads_total) {
+  extern __shared__ unsigned hist[];
+  constexpr int R = SPW * WPT;
+  const unsigned copies = 1u << copies_log2;
+  const unsigned my_copy = threadIdx.x & (copies - 1);
+  for (unsigned i = threadIdx.x; i < nbins * copies; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const size_t seq_len = info->seq_len;
+  const u64 kmask = (1ull << k) - 1;
+  unsigned mine = 0;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t p0 = t * R;
+    if (p0 >= seq_len) break;
+    u64 w[WPT + 1];
+#pragma unroll
+    for (int i = 0; i <= WPT; ++i) w[i] = codes[t * WPT + i];
+    const u64 badw = bad_window(bad, p0);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+#pragma unroll
+      for (int s = 0; s < SPW; ++s) {
+        if (((badw >> (i * SPW + s)) & kmask) == 0) {
+          unsigned key = (unsigned)window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+          atomicAdd(&hist[(key << copies_log2) | my_copy], 1u);
+          ++mine;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < nbins; b += blockDim.x) {
+    u64 sum = 0;
+    for (unsigned cpy = 0; cpy < copies; ++cpy) sum += hist[(b << copies_log2) | cpy];
+    if (sum) atomicAdd(&bins[b], sum);
+  }
+  add_windows(info, mine, false);
+}
+
+// ------------------------------------------------------------------------------- byref
+// Slot key = (tag << 40) | position; tag = 23 hash bits (bit 63 stays 0, so MK_EMPTY is free).
+#define REF_POS_BITS 40
+#define REF_POS_MASK ((1ull << REF_POS_BITS) - 1)
+
+__device__ __forceinline__ bool same_bytes(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int k) {
+  for (int i = 0; i < k; ++i)
+    if (a[i] != b[i]) return false;
+  return true;
+}
+
+__device__ __forceinline__ void insert_ref(MkSlot* __restrict__ table, u64 mask, const uint8_t* __restrict__ seq,
+                                           u64 pos, u64 h, int k, u64 add) {
+  const u64 tag = (h >> 41) << REF_POS_BITS;  // 23 bits
+  const u64 mine = tag | pos;
+  u64 slot = h & mask;
+  for (;;) {
+    u64 cur = table[slot].key;
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&table[slot].key, MK_EMPTY, mine);
+      if (cur == MK_EMPTY) {
+        atomicAdd(&table[slot].cnt, add);
+        return;
+      }
+    }
+    if ((cur & ~REF_POS_MASK) == tag && same_bytes(seq + (cur & REF_POS_MASK), seq + pos, k)) {
+      atomicAdd(&table[slot].cnt, add);
+      return;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__device__ __forceinline__ bool in_alphabet(int alphabet, unsigned c) {
+  if (alphabet == MK_ALPHABET_NT2) return c == 'A' || c == 'C' || c == 'G' || c == 'T';
+  return c >= 'A' && c <= 'Z';
+}
+
+// Each thread owns RB consecutive window starts. Rolling polynomial hash over the last k bytes.
+// EXOTIC: count only windows with >= 1 character outside `alphabet` (the packed kernel has the rest).
+#define RB 32
+template <bool EXOTIC>
+__global__ __launch_bounds__(256) void mk_count_byref_k(const uint8_t* __restrict__ seq, const u64* __restrict__ bad,
+                                                        MkChunkInfo* __restrict__ info, MkSlot* __restrict__ table,
+                                                        u64 mask, int k, int alphabet, u64 bpow /* B^k */) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t p0 = t * RB;
+  const size_t n = info->seq_len;
+  unsigned mine = 0;
+  bool work = p0 < n && p0 + k <= n;
+  if (EXOTIC && work) {
+    // skip quickly when no bad symbol lies in [p0, p0+RB+k-1): check the bitmap word by word
+    const size_t lo = p0, hi = p0 + RB + k - 1;  // exclusive
+    bool any = false;
+    for (size_t b = lo >> 6; b <= ((hi - 1) >> 6) && !any; ++b) {
+      u64 wv = bad[b];
+      size_t base = b << 6;
+      if (base < lo) wv &= ~0ull << (lo - base);
+      if (base + 64 > hi) wv &= ~0ull >> (base + 64 - hi);
+      any = wv != 0;
+    }
+    work = any;
+  }
+  if (work) {
+    u64 h = 0;
+    long long since_sep = 0;  // consecutive non-separator bytes ending at the current byte
+    long long since_bad = 1ll << 40;  // bytes since the last out-of-alphabet character (0 = current)
+    const size_t last = (p0 + RB - 1 + k <= n) ? p0 + RB - 1 + k : n;  // exclusive end of bytes to read
+    for (size_t e = p0; e < last; ++e) {
+      const unsigned ch = seq[e];
+      h = h * MK_POLY_B + ch;
+      if (e >= p0 + k) h -= bpow * (u64)seq[e - k];
+      if (ch == MK_SEP) { since_sep = 0; } else { ++since_sep; }
+      if (EXOTIC) { if (ch != MK_SEP && !in_alphabet(alphabet, ch)) since_bad = 0; else ++since_bad; }
+      if (e + 1 >= p0 + k) {  // window [e-k+1, e] starts at >= p0
+        if (since_sep >= k && (!EXOTIC || since_bad < k)) {
+          insert_ref(table, mask, seq, (u64)(e + 1 - k), mk_mix64(h), k, 1);
+          ++mine;
+        }
+      }
+    }
+  }
+  add_windows(info, mine, true);
+}
+
+// ------------------------------------------------------------------------------ launchers
+static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+
+int mk_launch_count_hash64(mk_ctx* c, size_t seq_len) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const u64 mask = c->ctab_slots - 1;
+  mk_prof_begin(c, MK_K_COUNT);
+  if (c->alphabet == MK_ALPHABET_NT2) {
+    const size_t threads = div_up(seq_len, 32);
+    hipLaunchKernelGGL((mk_count_hash64_k<2, 32, 1>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k);
+  } else {
+    const size_t threads = div_up(seq_len, 36);
+    hipLaunchKernelGGL((mk_count_hash64_k<5, 12, 3>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k);
+  }
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int mk_launch_count_dense(mk_ctx* c, size_t seq_len) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const unsigned nbins = 1u << (c->bits * c->k);
+  unsigned copies_log2 = 0;
+  while ((nbins << (copies_log2 + 1)) <= 8192u && copies_log2 < 5) ++copies_log2;
+  const size_t lds = (size_t)(nbins << copies_log2) * 4;
+  mk_prof_begin(c, MK_K_COUNT);
+  if (c->alphabet == MK_ALPHABET_NT2) {
+    const size_t threads = div_up(seq_len, 32);
+    size_t blocks = div_up(threads, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((mk_count_dense_k<2, 32, 1>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (u64*)c->ctab.p, nbins, copies_log2, c->k,
+                       threads);
+  } else {
+    const size_t threads = div_up(seq_len, 36);
+    size_t blocks = div_up(threads, 256);
+    const size_t cap = (lds > 65536) ? 256 : 2048;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((mk_count_dense_k<5, 12, 3>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (u64*)c->ctab.p, nbins, copies_log2, c->k,
+                       threads);
+  }
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+static u64 pow_u64(u64 b, int e) {
+  u64 r = 1;
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
+}
+
+int mk_launch_count_byref(mk_ctx* c, size_t seq_len, bool exotic_only) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const u64 mask = c->rtab_chunk_slots - 1;
+  const size_t threads = div_up(seq_len, RB);
+  const u64 bpow = pow_u64(MK_POLY_B, c->k);
+  mk_prof_begin(c, MK_K_EXOTIC);
+  if (exotic_only)
+    hipLaunchKernelGGL((mk_count_byref_k<true>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->seq.p, (const u64*)c->bad.p, info, (MkSlot*)c->rtab_chunk.p, mask, c->k,
+                       c->alphabet, bpow);
+  else
+    hipLaunchKernelGGL((mk_count_byref_k<false>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
+                       (const uint8_t*)c->seq.p, (const u64*)nullptr, info, (MkSlot*)c->rtab_chunk.p, mask, c->k,
+                       c->alphabet, bpow);
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}

@@ -1,0 +1,122 @@
+// mk_host.cpp -- host-side helpers behind the C ABI that need no GPU: the virtual Chunker and
+// the deterministic synthetic-read generator.
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include "../../include/mercat_hip.h"
+
+// ---------------------------------------------------------------------------- virtual Chunker
+// Restates Chunker.stream_delim (lib/mercat2_Chunker.py:39-59) without writing chunk files:
+// the reference iterates text-mode lines (universal newlines: "\n", "\r\n" and lone "\r" each
+// end a line and are written back as one "\n"), and when a line CONTAINS '>' and the bytes
+// written to the current chunk so far are >= chunksize, that line opens the next chunk.
+// We return the byte offsets (into the original, un-normalised text) where chunks 1.. begin.
+extern "C" int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, uint64_t* cuts, size_t cap,
+                             size_t* ncuts) {
+  if (!ncuts || (n && !text)) return MK_ERR_ARG;
+  size_t found = 0;
+  uint64_t written = 0;
+  size_t pos = 0;
+  while (pos < n) {
+    // find the end of this line: first '\n' or '\r' at or after pos
+    const uint8_t* p = text + pos;
+    const size_t left = n - pos;
+    const uint8_t* nl = (const uint8_t*)memchr(p, '\n', left);
+    size_t line_len = nl ? (size_t)(nl - p) : left;       // content length if terminated by \n
+    const uint8_t* cr = (const uint8_t*)memchr(p, '\r', line_len);
+    size_t term = 0;                                       // bytes of terminator in the raw text
+    if (cr) {
+      line_len = (size_t)(cr - p);
+      term = (pos + line_len + 1 < n && p[line_len + 1] == '\n') ? 2 : 1;
+    } else if (nl) {
+      term = 1;
+    }
+    const bool has_delim = memchr(p, '>', line_len) != nullptr;
+    if (has_delim && written >= chunksize) {
+      // (the very first line can only cut when chunksize == 0: chunk 0 is then empty)
+      if (found < cap && cuts) cuts[found] = (uint64_t)pos;
+      ++found;
+      written = 0;
+    }
+    written += line_len + (term ? 1 : 0);
+    pos += line_len + term;
+  }
+  *ncuts = found;
+  return (found > cap && cuts) ? MK_ERR_RANGE : MK_OK;
+}
+
+// ------------------------------------------------------------------------- synthetic reads
+static inline uint64_t splitmix64(uint64_t& s) {
+  s += 0x9E3779B97F4A7C15ull;
+  uint64_t z = s;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+static size_t dec_len(uint64_t v) {
+  size_t l = 1;
+  while (v >= 10) { v /= 10; ++l; }
+  return l;
+}
+
+extern "C" int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_t reads, uint32_t read_len,
+                              uint64_t read_seed, uint32_t sub_ppm, uint64_t first_index, uint8_t* out, size_t cap,
+                              size_t* written) {
+  if (!written || read_len == 0 || genome_len < read_len) return MK_ERR_ARG;
+  // size: ">r" + digits + "\n" + read_len + "\n"
+  size_t total = 0;
+  {
+    uint64_t i = first_index, end = first_index + reads;
+    while (i < end) {  // group indices by decimal length
+      size_t l = dec_len(i);
+      uint64_t lim = 1;
+      for (size_t d = 0; d < l; ++d) lim *= 10;  // first index with one more digit
+      uint64_t hi = end < lim ? end : lim;
+      total += (size_t)(hi - i) * (2 + l + 1 + read_len + 1);
+      i = hi;
+    }
+  }
+  *written = total;
+  if (!out) return MK_OK;
+  if (cap < total) return MK_ERR_RANGE;
+  // genome: 2-bit codes, 32 bases per splitmix64 draw (base j of a draw = bits 2j..2j+1)
+  std::vector<uint8_t> g(genome_len);
+  {
+    uint64_t s = genome_seed;
+    for (uint64_t i = 0; i < genome_len; i += 32) {
+      uint64_t r = splitmix64(s);
+      uint64_t m = genome_len - i < 32 ? genome_len - i : 32;
+      for (uint64_t j = 0; j < m; ++j) g[i + j] = (uint8_t)((r >> (2 * j)) & 3);
+    }
+  }
+  static const char L[4] = {'A', 'C', 'G', 'T'};
+  uint8_t* w = out;
+  const uint64_t span = genome_len - read_len + 1;
+  for (uint64_t r = 0; r < reads; ++r) {
+    const uint64_t idx = first_index + r;
+    uint64_t s = read_seed + idx * 0x632BE59BD9B4E019ull;
+    const uint64_t start = splitmix64(s) % span;
+    const bool rc = (splitmix64(s) >> 63) != 0;
+    *w++ = '>';
+    *w++ = 'r';
+    char num[24];
+    int len = 0;
+    uint64_t v = idx;
+    do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (len) *w++ = (uint8_t)num[--len];
+    *w++ = '\n';
+    for (uint32_t j = 0; j < read_len; ++j) {
+      unsigned b = rc ? (3u - g[start + read_len - 1 - j]) : g[start + j];
+      if (sub_ppm) {
+        uint64_t d = splitmix64(s);
+        if (d % 1000000ull < sub_ppm) b = (b + 1 + (unsigned)((d >> 32) % 3)) & 3u;
+      }
+      *w++ = (uint8_t)L[b];
+    }
+    *w++ = '\n';
+  }
+  return MK_OK;
+}

@@ -1,0 +1,304 @@
+// mk_table.hip -- chunk-table -> running-table kernels.
+//
+// Replaces (a) the per-file min_count filter of find_kmers (lib/mercat2_kmers.py:73-76: keep a
+// key iff its count IN THIS FILE/CHUNK is >= min_count) and (b) run_mercat2's merge of the
+// surviving dicts (bin/mercat2.py:121-127: kmers[k] += v).  The filter is applied per chunk,
+// before the merge -- there is no post-merge filter in the reference (SURVEY.md trap T2).
+#include "mk_common.h"
+
+typedef unsigned long long u64;
+#define REF_POS_BITS 40
+#define REF_POS_MASK ((1ull << REF_POS_BITS) - 1)
+
+static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+static unsigned grid_for(size_t items, unsigned per_block = 256, unsigned cap = 1u << 20) {
+  size_t g = div_up(items, per_block);
+  if (g > cap) g = cap;
+  if (g == 0) g = 1;
+  return (unsigned)g;
+}
+
+// ----------------------------------------------------------------------------------- clear
+__global__ void mk_clear_slots_k(MkSlot* __restrict__ t, size_t slots) {
+  const ulonglong2 e = make_ulonglong2(MK_EMPTY, 0ull);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x)
+    reinterpret_cast<ulonglong2*>(t)[i] = e;
+}
+
+int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots) {
+  if (!slots) return MK_OK;
+  hipLaunchKernelGGL(mk_clear_slots_k, dim3(grid_for(slots, 256, 16384)), dim3(256), 0, c->stream, t, slots);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------------------ survivors
+__device__ __forceinline__ void block_add(u64* target, u64 mine) {
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(target, mine);
+}
+
+__global__ void mk_count_survivors_k(const MkSlot* __restrict__ t, size_t slots, u64 min_count, u64* __restrict__ out) {
+  u64 mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(t)[i];
+    mine += (s.x != MK_EMPTY && s.y >= min_count) ? 1 : 0;
+  }
+  block_add(out, mine);
+}
+
+int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  if (c->mode == MK_MODE_HASH64 && c->ctab_slots)
+    hipLaunchKernelGGL(mk_count_survivors_k, dim3(grid_for(c->ctab_slots, 256, 8192)), dim3(256), 0, c->stream,
+                       (const MkSlot*)c->ctab.p, c->ctab_slots, (u64)min_count, &info->survivors);
+  if (c->rtab_chunk_slots)
+    hipLaunchKernelGGL(mk_count_survivors_k, dim3(grid_for(c->rtab_chunk_slots, 256, 8192)), dim3(256), 0, c->stream,
+                       (const MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots, (u64)min_count, &info->survivors_ref);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// ------------------------------------------------------------------- running table: hash64
+// Returns true when the key was new to the table.
+__device__ __forceinline__ bool upsert64(MkSlot* __restrict__ table, u64 mask, u64 key, u64 add) {
+  u64 slot = mk_mix64(key) & mask;
+  for (;;) {
+    u64 cur = table[slot].key;
+    bool fresh = false;
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&table[slot].key, MK_EMPTY, key);
+      if (cur == MK_EMPTY) { cur = key; fresh = true; }
+    }
+    if (cur == key) {
+      atomicAdd(&table[slot].cnt, add);
+      return fresh;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__global__ void mk_accumulate64_k(const MkSlot* __restrict__ from, size_t slots, u64 min_count, MkSlot* __restrict__ run,
+                                  u64 run_mask, u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
+    if (s.x != MK_EMPTY && s.y >= min_count && s.y != 0) fresh += upsert64(run, run_mask, s.x, s.y) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+
+__global__ void mk_import_pairs_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
+                                  MkSlot* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)
+    if (cnts[i]) fresh += upsert64(run, run_mask, keys[i], cnts[i]) ? 1 : 0;
+  block_add(new_rows, fresh);
+}
+
+__global__ void mk_import_bins_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
+                                 u64* __restrict__ bins, size_t nbins) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)
+    if (keys[i] < nbins) atomicAdd(&bins[keys[i]], cnts[i]);
+}
+
+// ------------------------------------------------------------------- running table: dense
+__global__ void mk_accumulate_dense_k(u64* __restrict__ chunk, size_t nbins, u64 min_count, u64* __restrict__ run) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (size_t)gridDim.x * blockDim.x) {
+    u64 v = chunk[i];
+    if (v >= min_count && v) run[i] += v;
+    chunk[i] = 0;
+  }
+}
+
+// --------------------------------------------------------------- running table: by reference
+// Running slot key = (tag << 40) | arena row; the k bytes of row r live at arena[r*k .. r*k+k).
+// Arena bytes written in this launch are read by other workgroups of the same launch, so they
+// are read with agent-scope loads (never from a stale L1 line).
+__device__ __forceinline__ unsigned ld_u8_agent(const uint8_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ u64 poly_hash(const uint8_t* __restrict__ s, int k) {
+  u64 h = 0;
+  for (int i = 0; i < k; ++i) h = h * MK_POLY_B + s[i];
+  return mk_mix64(h);
+}
+
+__device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, uint8_t* __restrict__ arena,
+                                           const uint8_t* __restrict__ str, int k, u64 add, u64 arena_base,
+                                           u64* __restrict__ new_rows) {
+  const u64 h = poly_hash(str, k);
+  const u64 tag = (h >> 41) << REF_POS_BITS;
+  u64 slot = h & mask;
+  u64 my_row = MK_EMPTY;
+  for (;;) {
+    u64 cur = __hip_atomic_load(&run[slot].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == MK_EMPTY) {
+      if (my_row == MK_EMPTY) {
+        my_row = arena_base + atomicAdd(new_rows, 1ull);
+        uint8_t* dst = arena + my_row * (u64)k;
+        for (int i = 0; i < k; ++i) __hip_atomic_store(dst + i, str[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+      }
+      cur = atomicCAS(&run[slot].key, MK_EMPTY, tag | my_row);
+      if (cur == MK_EMPTY) {
+        atomicAdd(&run[slot].cnt, add);
+        return true;
+      }
+    }
+    if ((cur & ~REF_POS_MASK) == tag && my_row == MK_EMPTY) {
+      const uint8_t* other = arena + (cur & REF_POS_MASK) * (u64)k;
+      bool same = true;
+      for (int i = 0; i < k && same; ++i) same = ld_u8_agent(other + i) == str[i];
+      if (same) {
+        atomicAdd(&run[slot].cnt, add);
+        return false;
+      }
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// Survivors of the by-reference chunk table -> running by-reference table. Within one launch
+// every inserted string is distinct (they come from distinct chunk slots), so once a thread
+// has reserved an arena row (my_row) its string is known to be new and it only looks for a
+// free slot.
+__global__ void mk_accumulate_ref_k(const MkSlot* __restrict__ from, size_t slots, u64 min_count,
+                                    const uint8_t* __restrict__ seq, int k, MkSlot* __restrict__ run, u64 run_mask,
+                                    uint8_t* __restrict__ arena, u64 arena_base, u64* __restrict__ new_rows) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
+    if (s.x != MK_EMPTY && s.y >= min_count && s.y != 0)
+      upsert_ref(run, run_mask, arena, seq + (s.x & REF_POS_MASK), k, s.y, arena_base, new_rows);
+  }
+}
+
+// Strings from a staging buffer (rows*k bytes), e.g. rows received from another GPU. Distinct
+// among themselves as well (they are rows of one table).
+__global__ void mk_import_ref_k(const uint8_t* __restrict__ strs, const u64* __restrict__ cnts, size_t rows, int k,
+                                MkSlot* __restrict__ run, u64 run_mask, uint8_t* __restrict__ arena, u64 arena_base,
+                                u64* __restrict__ new_rows) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)
+    if (cnts[i]) upsert_ref(run, run_mask, arena, strs + i * (size_t)k, k, cnts[i], arena_base, new_rows);
+}
+
+// Re-insert after growth: rows are distinct and their bytes are final -> only find a free slot.
+__global__ void mk_rehash_ref_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, u64 to_mask,
+                                const uint8_t* __restrict__ arena, int k) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
+    if (s.x == MK_EMPTY) continue;
+    const u64 h = poly_hash(arena + (s.x & REF_POS_MASK) * (u64)k, k);
+    u64 slot = h & to_mask;
+    for (;;) {
+      if (atomicCAS(&to[slot].key, MK_EMPTY, s.x) == MK_EMPTY) {
+        to[slot].cnt = s.y;
+        break;
+      }
+      slot = (slot + 1) & to_mask;
+    }
+  }
+}
+
+__global__ void mk_rehash64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, u64 to_mask) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
+    if (s.x == MK_EMPTY) continue;
+    u64 slot = mk_mix64(s.x) & to_mask;
+    for (;;) {
+      if (atomicCAS(&to[slot].key, MK_EMPTY, s.x) == MK_EMPTY) {
+        to[slot].cnt = s.y;
+        break;
+      }
+      slot = (slot + 1) & to_mask;
+    }
+  }
+}
+
+int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots) {
+  if (!from_slots) return MK_OK;
+  hipLaunchKernelGGL(mk_rehash64_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots, to,
+                     (u64)(to_slots - 1));
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots) {
+  if (!from_slots) return MK_OK;
+  hipLaunchKernelGGL(mk_rehash_ref_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots,
+                     to, (u64)(to_slots - 1), (const uint8_t*)c->arena.p, c->k);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// Filter + merge of the chunk tables into the running tables (capacities already ensured).
+int mk_launch_accumulate(mk_ctx* c, uint64_t min_count) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  mk_prof_begin(c, MK_K_FILTER);
+  if (c->mode == MK_MODE_DENSE) {
+    const size_t nbins = (size_t)1 << (c->bits * c->k);
+    hipLaunchKernelGGL(mk_accumulate_dense_k, dim3(grid_for(nbins)), dim3(256), 0, c->stream, (u64*)c->ctab.p, nbins,
+                       (u64)min_count, (u64*)c->run.p);
+  } else if (c->mode == MK_MODE_HASH64 && c->ctab_slots && c->h_info->survivors) {
+    hipLaunchKernelGGL(mk_accumulate64_k, dim3(grid_for(c->ctab_slots, 256, 8192)), dim3(256), 0, c->stream,
+                       (const MkSlot*)c->ctab.p, c->ctab_slots, (u64)min_count, (MkSlot*)c->run.p,
+                       (u64)(c->run_slots - 1), &info->new_rows);
+  }
+  if (c->rtab_chunk_slots && c->h_info->survivors_ref) {
+    hipLaunchKernelGGL(mk_accumulate_ref_k, dim3(grid_for(c->rtab_chunk_slots, 256, 8192)), dim3(256), 0, c->stream,
+                       (const MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots, (u64)min_count, (const uint8_t*)c->seq.p,
+                       c->k, (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1), (uint8_t*)c->arena.p,
+                       (u64)c->run_ref_rows, &info->new_rows_ref);
+  }
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
+  if (!rows) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  if (c->mode == MK_MODE_DENSE) {
+    const size_t nbins = (size_t)1 << (c->bits * c->k);
+    hipLaunchKernelGGL(mk_import_bins_k, dim3(grid_for(rows)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                       (const u64*)d_counts, rows, (u64*)c->run.p, nbins);
+  } else {
+    hipLaunchKernelGGL(mk_import_pairs_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows);
+  }
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows) {
+  if (!rows) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_import_ref_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, d_kmers,
+                     (const u64*)d_counts, rows, c->k, (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1),
+                     (uint8_t*)c->arena.p, (u64)c->run_ref_rows, &info->new_rows_ref);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// --------------------------------------------------------------------------------- compact
+// Occupied slots of a table -> (keys, counts) in arbitrary order; *cursor counts them.
+__global__ void mk_compact_k(const MkSlot* __restrict__ t, size_t slots, u64* __restrict__ keys, u64* __restrict__ cnts,
+                             size_t cap, u64* __restrict__ cursor) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(t)[i];
+    if (s.x != MK_EMPTY && s.y != 0) {
+      u64 at = atomicAdd(cursor, 1ull);
+      if (at < cap) { keys[at] = s.x; cnts[at] = s.y; }
+    }
+  }
+}
+
+int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys, uint64_t* d_counts, size_t cap,
+                      uint64_t* d_cursor) {
+  if (!slots) return MK_OK;
+  hipLaunchKernelGGL(mk_compact_k, dim3(grid_for(slots, 256, 8192)), dim3(256), 0, c->stream, t, slots, (u64*)d_keys,
+                     (u64*)d_counts, cap, (u64*)d_cursor);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}

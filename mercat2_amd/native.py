@@ -1,0 +1,271 @@
+"""ctypes binding of libmercat_hip.so (C ABI: include/mercat_hip.h).
+
+The library is looked up next to this file (it is built in-tree by
+``__graft_entry__.build()`` / ``make -C mercat2_amd/csrc``).  A missing library or a missing
+HIP device raises -- nothing here or above falls back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Tuple
+
+import numpy as np
+
+ALPHABET_NT2, ALPHABET_AA5, ALPHABET_RAW = 0, 1, 2
+MODE_NAMES = {0: "dense", 1: "hash64", 2: "hash128", 3: "byref"}
+
+MK_OK = 0
+ERR_NAMES = {-1: "MK_ERR_ARG", -2: "MK_ERR_HIP", -3: "MK_ERR_NOMEM", -4: "MK_ERR_STATE",
+             -5: "MK_ERR_NON_ASCII", -6: "MK_ERR_IO", -7: "MK_ERR_RANGE"}
+
+# every symbol include/mercat_hip.h declares (tests check the library exports each of them)
+ABI_SYMBOLS = [
+    "mk_create", "mk_destroy", "mk_last_error", "mk_reset", "mk_chunk_begin", "mk_chunk_feed",
+    "mk_chunk_feed_device", "mk_chunk_end", "mk_count_device", "mk_export_size", "mk_export",
+    "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
+    "mk_import_exotic", "mk_words_per_key", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
+    "mk_chunk_cuts", "mk_synth_reads", "mk_version",
+]
+
+
+class MercatHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("%s (%d): %s" % (ERR_NAMES.get(code, "MK_ERR"), code, message))
+        self.code = code
+
+
+class NonAsciiInput(MercatHipError, UnicodeDecodeError.__base__):  # ValueError family, like a decode error
+    pass
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("raw_bytes", "symbols", "windows", "exotic_windows", "chunks",
+                                           "survivors", "rows", "table_slots")] + \
+               [("mode", C.c_int32), ("profiled", C.c_int32)] + \
+               [(n, C.c_double) for n in ("ms_parse", "ms_pack", "ms_count", "ms_exotic", "ms_filter", "ms_export")] + \
+               [(n, C.c_uint64) for n in ("n_parse", "n_pack", "n_count", "n_exotic", "n_filter", "n_export")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_LIB: Optional[C.CDLL] = None
+
+
+def library_path() -> Path:
+    return Path(os.environ.get("MERCAT_HIP_LIB", Path(__file__).resolve().parent / "libmercat_hip.so"))
+
+
+def lib() -> C.CDLL:
+    """Load libmercat_hip.so once; raise if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not path.exists():
+        raise MercatHipError(-2, "HIP extension %s is missing: build it with `python -c 'import __graft_entry__ as g; "
+                                 "g.build()'` or `make -C mercat2_amd/csrc` (there is no CPU fallback)" % path)
+    L = C.CDLL(str(path))
+    vp, u8p, u64p, szp = C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)
+    sig = {
+        "mk_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+        "mk_destroy": (None, [vp]),
+        "mk_last_error": (C.c_char_p, [vp]),
+        "mk_reset": (C.c_int, [vp]),
+        "mk_chunk_begin": (C.c_int, [vp]),
+        "mk_chunk_feed": (C.c_int, [vp, u8p, C.c_size_t]),
+        "mk_chunk_feed_device": (C.c_int, [vp, u8p, C.c_size_t]),
+        "mk_chunk_end": (C.c_int, [vp, C.c_uint64]),
+        "mk_count_device": (C.c_int, [vp, u8p, C.c_size_t, C.c_uint64]),
+        "mk_export_size": (C.c_int, [vp, szp]),
+        "mk_export": (C.c_int, [vp, u8p, u64p, C.c_size_t]),
+        "mk_write_tsv": (C.c_int, [vp, C.c_char_p, C.c_char_p, szp]),
+        "mk_export_pairs_device": (C.c_int, [vp, u64p, u64p, C.c_size_t, szp]),
+        "mk_import_pairs_device": (C.c_int, [vp, u64p, u64p, C.c_size_t]),
+        "mk_export_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t, szp]),
+        "mk_import_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t]),
+        "mk_words_per_key": (C.c_int, [vp]),
+        "mk_set_profiling": (C.c_int, [vp, C.c_int]),
+        "mk_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
+        "mk_reset_stats": (C.c_int, [vp]),
+        "mk_chunk_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, u64p, C.c_size_t, szp]),
+        "mk_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
+                                     C.c_uint64, u8p, C.c_size_t, szp]),
+        "mk_version": (C.c_char_p, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = L
+    return L
+
+
+def _buf_ptr(data) -> Tuple[int, int, object]:
+    """(address, nbytes, keepalive) of a bytes-like object without copying."""
+    if isinstance(data, np.ndarray):
+        a = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+        return a.ctypes.data, a.nbytes, a
+    mv = memoryview(data)
+    if mv.nbytes == 0:
+        return 0, 0, None
+    a = np.frombuffer(mv, dtype=np.uint8)
+    return a.ctypes.data, a.nbytes, a
+
+
+# ------------------------------------------------------------------------------ host helpers
+def chunk_cuts(text, chunksize: int) -> np.ndarray:
+    """Offsets at which the reference Chunker would start chunks 1.. (lib/mercat2_Chunker.py:39-59)."""
+    L = lib()
+    addr, n, keep = _buf_ptr(text)
+    need = C.c_size_t(0)
+    cap = 64
+    while True:
+        cuts = np.empty(cap, dtype=np.uint64)
+        rc = L.mk_chunk_cuts(addr, n, int(chunksize), cuts.ctypes.data, cap, C.byref(need))
+        if rc == MK_OK:
+            return cuts[: need.value].copy()
+        if rc != -7:
+            raise MercatHipError(rc, "mk_chunk_cuts")
+        cap = need.value
+
+
+def synth_reads(genome_len: int, genome_seed: int, reads: int, read_len: int, read_seed: int,
+                sub_ppm: int = 0, first_index: int = 0) -> np.ndarray:
+    """Deterministic synthetic FASTA reads as a uint8 array."""
+    L = lib()
+    size = C.c_size_t(0)
+    rc = L.mk_synth_reads(genome_len, genome_seed, reads, read_len, read_seed, sub_ppm, first_index, None, 0, C.byref(size))
+    if rc:
+        raise MercatHipError(rc, "mk_synth_reads(size)")
+    out = np.empty(size.value, dtype=np.uint8)
+    rc = L.mk_synth_reads(genome_len, genome_seed, reads, read_len, read_seed, sub_ppm, first_index,
+                          out.ctypes.data, out.nbytes, C.byref(size))
+    if rc:
+        raise MercatHipError(rc, "mk_synth_reads")
+    return out
+
+
+# ----------------------------------------------------------------------------------- context
+class Counter:
+    """One GPU counting context for a fixed (alphabet, k): wraps mk_ctx."""
+
+    def __init__(self, k: int, alphabet: int = ALPHABET_NT2, device: int = 0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        self.k, self.alphabet, self.device = int(k), int(alphabet), int(device)
+        rc = self._L.mk_create(self.device, self.alphabet, self.k, C.byref(self._h))
+        if rc:
+            msg = self._L.mk_last_error(None)
+            raise MercatHipError(rc, msg.decode() if msg else "mk_create")
+
+    # -- plumbing
+    def _check(self, rc: int):
+        if rc:
+            msg = self._L.mk_last_error(self._h)
+            text = msg.decode() if msg else ""
+            raise (NonAsciiInput if rc == -5 else MercatHipError)(rc, text)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._L.mk_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- counting
+    def reset(self):
+        self._check(self._L.mk_reset(self._h))
+
+    def count_chunk(self, data, min_count: int):
+        """One reference find_kmers call: count ``data`` (raw FASTA bytes), keep >= min_count,
+        add the survivors into the running table."""
+        addr, n, keep = _buf_ptr(data)
+        self._check(self._L.mk_chunk_begin(self._h))
+        try:
+            if n:
+                self._check(self._L.mk_chunk_feed(self._h, addr, n))
+        except Exception:
+            self._L.mk_chunk_end(self._h, 0)
+            raise
+        self._check(self._L.mk_chunk_end(self._h, int(min_count)))
+
+    def count_device(self, ptr: int, nbytes: int, min_count: int):
+        """Count FASTA bytes already resident in this GPU's memory (ptr = device address)."""
+        self._check(self._L.mk_count_device(self._h, ptr, int(nbytes), int(min_count)))
+
+    # -- results
+    def rows(self) -> int:
+        n = C.c_size_t(0)
+        self._check(self._L.mk_export_size(self._h, C.byref(n)))
+        return n.value
+
+    def export(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(kmers as a (rows, k) uint8 array, counts uint64) in sorted order."""
+        rows = self.rows()
+        kmers = np.empty((rows, self.k), dtype=np.uint8)
+        counts = np.empty(rows, dtype=np.uint64)
+        self._check(self._L.mk_export(self._h, kmers.ctypes.data, counts.ctypes.data, rows))
+        return kmers, counts
+
+    def to_dict(self) -> dict:
+        kmers, counts = self.export()
+        if kmers.shape[0] == 0:
+            return {}
+        flat = kmers.tobytes().decode("ascii")
+        k = self.k
+        return dict(zip((flat[i:i + k] for i in range(0, len(flat), k)), counts.tolist()))
+
+    def write_tsv(self, path, basename: str) -> int:
+        n = C.c_size_t(0)
+        self._check(self._L.mk_write_tsv(self._h, os.fsencode(str(path)), basename.encode(), C.byref(n)))
+        return n.value
+
+    # -- multi-GPU plumbing (device pointers come from torch tensors)
+    def export_pairs_device(self, keys_ptr: int, counts_ptr: int, cap: int) -> int:
+        n = C.c_size_t(0)
+        self._check(self._L.mk_export_pairs_device(self._h, keys_ptr, counts_ptr, cap, C.byref(n)))
+        return n.value
+
+    def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
+        self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
+
+    def export_exotic(self) -> Tuple[np.ndarray, np.ndarray]:
+        n = C.c_size_t(0)
+        self._check(self._L.mk_export_exotic(self._h, None, None, 0, C.byref(n)))
+        kmers = np.empty((n.value, self.k), dtype=np.uint8)
+        counts = np.empty(n.value, dtype=np.uint64)
+        if n.value:
+            self._check(self._L.mk_export_exotic(self._h, kmers.ctypes.data, counts.ctypes.data, n.value, C.byref(n)))
+        return kmers, counts
+
+    def import_exotic(self, kmers: np.ndarray, counts: np.ndarray):
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+        counts = np.ascontiguousarray(counts, dtype=np.uint64)
+        if counts.size:
+            self._check(self._L.mk_import_exotic(self._h, kmers.ctypes.data, counts.ctypes.data, counts.size))
+
+    # -- stats
+    def set_profiling(self, on: bool):
+        self._check(self._L.mk_set_profiling(self._h, 1 if on else 0))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._check(self._L.mk_get_stats(self._h, C.byref(s)))
+        d = s.as_dict()
+        d["mode_name"] = MODE_NAMES.get(d["mode"], "?")
+        return d
+
+    def reset_stats(self):
+        self._check(self._L.mk_reset_stats(self._h))

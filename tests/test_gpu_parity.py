@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+
+Bit-exact is the bar: integer counts, identical key sets, identical sorted TSV text.
+Run with ``pytest -m gpu`` on an MI355X box; nothing here reads /root/reference.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, read_input
+from mercat2_amd import native
+from mercat2_amd.chunker import chunk_offsets
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+EXPECTED = json.loads((GOLDEN / "expected.json").read_text())
+CHUNKS = json.loads((GOLDEN / "chunks.json").read_text())
+
+
+def tsv_of(ctx, base):
+    kmers, counts = ctx.export()
+    k = ctx.k
+    flat = kmers.tobytes().decode("ascii")
+    rows = ["k-mer\t%s_Count\n" % base]
+    rows += ["%s\t%d\n" % (flat[i * k:(i + 1) * k], int(c)) for i, c in enumerate(counts)]
+    return "".join(rows)
+
+
+def digest_of(ctx, base):
+    kmers, counts = ctx.export()
+    text = tsv_of(ctx, base)
+    return {"rows": int(counts.size), "sum": int(counts.sum()), "sha256": hashlib.sha256(text.encode()).hexdigest()}
+
+
+def alphabet_for(name):
+    return native.ALPHABET_AA5 if ".faa" in name else native.ALPHABET_NT2
+
+
+def _grouped():
+    groups = {}
+    for case in EXPECTED.values():
+        groups.setdefault(case["input"], []).append(case)
+    return sorted(groups.items())
+
+
+@pytest.mark.parametrize("fname,cases", _grouped(), ids=[g[0] for g in _grouped()])
+def test_golden_matrix(fname, cases):
+    """Every (input, k, c) golden of the reference, through the natural alphabet."""
+    data = read_input(fname)
+    for case in sorted(cases, key=lambda c: (c["k"], c["c"])):
+        with native.Counter(case["k"], alphabet_for(fname)) as ctx:
+            ctx.count_chunk(data, case["c"])
+            got = digest_of(ctx, case["basename"])
+        assert got == {k: case[k] for k in ("rows", "sum", "sha256")}, (fname, case["k"], case["c"], ctx.stats()["mode_name"])
+
+
+@pytest.mark.parametrize("alphabet", [native.ALPHABET_RAW, native.ALPHABET_NT2, native.ALPHABET_AA5],
+                         ids=["raw", "nt2", "aa5"])
+def test_any_alphabet_gives_the_same_answer(alphabet):
+    """The alphabet only selects the packed fast path; windows outside it go by reference."""
+    for fname, ks in [("edge_ws.fa", [1, 3, 5, 13, 31, 64]), ("edge_lengths.fa", [2, 5, 13, 21, 32, 33]),
+                      ("edge_protein.faa", [1, 3, 5, 12, 13]), ("A.fasta", [5, 31])]:
+        data = read_input(fname)
+        for k in ks:
+            for c in (1, 2):
+                case = EXPECTED["%s|k%d|c%d" % (fname, k, c)]
+                with native.Counter(k, alphabet) as ctx:
+                    ctx.count_chunk(data, c)
+                    got = digest_of(ctx, case["basename"])
+                assert got == {x: case[x] for x in ("rows", "sum", "sha256")}, (fname, k, c, alphabet)
+
+
+def test_dict_equals_oracle_dict():
+    for fname, k, c in [("edge_ws.fa", 5, 1), ("edge_reads.fna", 21, 2), ("edge_protein.faa", 3, 1),
+                        ("Scaffolds_with-NNN.fna.gz", 5, 10), ("edge_lengths.fa", 32, 1), ("edge_lengths.fa", 64, 1)]:
+        data = read_input(fname)
+        with native.Counter(k, alphabet_for(fname)) as ctx:
+            ctx.count_chunk(data, c)
+            got = ctx.to_dict()
+        assert got == cpu_ref.count_text(data, k, c), (fname, k, c)
+
+
+def test_committed_reference_tables(tmp_path):
+    """results/2023-11-29/*/tsv_*/*_counts.tsv of the reference, byte for byte, via mk_write_tsv,
+    including the 3-chunk DJ_pro case (per-chunk filter before the merge)."""
+    for tsv, meta in CHUNKS["committed_tables"].items():
+        data = read_input(meta["input"])
+        size = meta["chunk_mib"] * 1024 * 1024
+        offs = chunk_offsets(data, size) if meta["chunk_mib"] and len(data) >= size else [0, len(data)]
+        out = tmp_path / tsv
+        with native.Counter(meta["k"], alphabet_for(meta["input"])) as ctx:
+            for a, b in zip(offs[:-1], offs[1:]):
+                ctx.count_chunk(memoryview(data)[a:b], meta["c"])
+            rows = ctx.write_tsv(out, meta["basename"])
+        want = (GOLDEN / "tsv" / tsv).read_text()
+        assert rows == want.count("\n") - 1
+        assert out.read_text() == want, tsv
+
+
+def test_chunked_counts_match_reference_chunker():
+    for name, g in CHUNKS["chunks"].items():
+        data = read_input(g["input"])
+        offs = chunk_offsets(data, g["bytes"])
+        assert len(offs) - 1 == len(g["names"]), name
+        for kc, want in g["counts"].items():
+            k, c = int(kc.split("|")[0][1:]), int(kc.split("|")[1][1:])
+            with native.Counter(k, alphabet_for(g["input"])) as ctx:
+                for a, b in zip(offs[:-1], offs[1:]):
+                    ctx.count_chunk(memoryview(data)[a:b], c)
+                base = g["input"]
+                for ext in (".faa.gz", ".fna.gz", ".fasta", ".fna", ".faa", ".fa"):
+                    if base.endswith(ext):
+                        base = base[: -len(ext)]
+                        break
+                assert digest_of(ctx, base) == want, (name, kc)
+
+
+def test_no_tsv_when_nothing_survives(tmp_path):
+    data = read_input("A.fasta")
+    out = tmp_path / "none.tsv"
+    with native.Counter(31, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, 1000)
+        assert ctx.write_tsv(out, "A") == 0
+        assert ctx.rows() == 0
+    assert not out.exists()
+
+
+def test_empty_and_ragged_inputs():
+    for data in [b"", b"\n\n", b">only header", b">h\nAC\n", b"ACGT", b">a\n>b\n>c\n", b"\r\r\n\r"]:
+        for k in (1, 3, 31, 33):
+            for alpha in (native.ALPHABET_NT2, native.ALPHABET_RAW):
+                with native.Counter(k, alpha) as ctx:
+                    ctx.count_chunk(data, 1)
+                    assert ctx.to_dict() == cpu_ref.count_text(data, k, 1), (data, k, alpha)
+
+
+def test_non_ascii_is_refused():
+    with native.Counter(3, native.ALPHABET_NT2) as ctx:
+        with pytest.raises(native.MercatHipError) as e:
+            ctx.count_chunk(">r\nAC\xc3\xa9GT\n".encode("latin-1"), 1)
+        assert e.value.code == -5
+        ctx.count_chunk(b">r\nACGT\n", 1)  # the context stays usable
+        assert ctx.to_dict() == {"ACG": 1, "CGT": 1}
+
+
+def test_reset_and_reuse():
+    a, b = read_input("A.fasta"), read_input("B.fasta")
+    with native.Counter(21, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(a, 1)
+        ctx.count_chunk(b, 1)
+        both = ctx.to_dict()
+        ctx.reset()
+        ctx.count_chunk(b, 1)
+        only_b = ctx.to_dict()
+    assert only_b == cpu_ref.count_text(b, 21, 1)
+    assert both == cpu_ref.merge_counts([cpu_ref.count_text(a, 21, 1), cpu_ref.count_text(b, 21, 1)])
+
+
+def _synth(reads, k, genome=200_000, sub_ppm=0):
+    return native.synth_reads(genome, 11, reads, 150, 12, sub_ppm).tobytes()
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_synthetic_reads_vs_oracle(k):
+    """60k x 150 bp reads from a 200 kbp genome (9 Mbases): full dict equality with the oracle."""
+    data = _synth(60_000, k)
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, 10)
+        got = ctx.to_dict()
+        st = ctx.stats()
+    want = cpu_ref.count_text(data, k, 10)
+    assert got == want
+    assert st["symbols"] == 60_000 * 150 and st["windows"] == 60_000 * (150 - k + 1)
+
+
+def test_full_size_properties_config2():
+    """BASELINE config 2 size (1M x 150 bp, k=21): size-independent properties.
+    (a) sum of counts at c=1 == number of windows; (b) counting in 2 pieces at c=1 equals
+    counting in one piece (linearity of the merge); (c) rows sorted strictly ascending."""
+    k = 21
+    data = native.synth_reads(1_000_000, 1, 1_000_000, 150, 2).tobytes()
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, 1)
+        kmers, counts = ctx.export()
+        st = ctx.stats()
+    assert int(counts.sum()) == 1_000_000 * (150 - k + 1) == st["windows"]
+    keys = kmers.view("S%d" % k).reshape(-1)
+    assert np.all(keys[:-1] < keys[1:])
+    cut = chunk_offsets(data, len(data) // 2)
+    assert len(cut) == 3
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(memoryview(data)[cut[0]:cut[1]], 1)
+        ctx.count_chunk(memoryview(data)[cut[1]:cut[2]], 1)
+        kmers2, counts2 = ctx.export()
+    assert np.array_equal(kmers, kmers2) and np.array_equal(counts, counts2)
