@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: bases/s of the k-mer counting hot path on MI355X.
+
+Workload (BASELINE.json metric: "bases/sec at k=31, 10M x 150bp"; SURVEY.md 8d "S2"):
+  10,000,000 reads x 150 bp sampled (both strands) from a 10 Mbp iid genome (seeds 3/4),
+  FASTA text ~1.6 GB, k=31, forward-strand keys (reference behaviour), -c 10, -s 100:
+  the reference's Chunker cut points (>= 100 MiB chunks, ~16 of them) are the filter units.
+One "step" = the whole sample once: for every chunk  raw FASTA bytes (already resident in HBM)
+  -> GPU parse -> 2-bit pack -> count -> keep count >= 10 -> add into the running table,
+  then the sorted (key,count) export of the merged table on the device (+ for N > 1 the
+  key-range all-to-all merge across ranks over RCCL).  value = bases of all ranks / time.
+N > 1 (weak scaling): every rank counts its own 10M reads (same genome, disjoint read
+  indices), then the ranks merge their tables.
+
+Extra objects on the JSON line:
+  roofline     dominant kernel = the hash-table count kernel; achieved = algorithmic bytes per
+               launch (windows*16 B + symbols*0.25 B) / mean launch time measured
+               with HIP events on the engine's stream; peak = 8 TB/s HBM3E.
+  cpu_baseline the CPU oracle (Python restatement of the reference, oracle/cpu_ref.py) timed on
+               this box's host cores on a bounded sample at the same coverage.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+GENOME, GENOME_SEED, READS, READ_LEN, READ_SEED = 10_000_000, 3, 10_000_000, 150, 4
+K, MIN_COUNT, CHUNK_MIB = 31, 10, 100
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_sample_worker(args):
+    """One CPU 'chunk': reads at the benchmark's coverage from a small genome, counted by the oracle."""
+    from oracle import cpu_ref
+    from mercat2_amd import native
+    idx, reads, k, c = args
+    data = native.synth_reads(reads, 100 + idx, reads, READ_LEN, 200 + idx).tobytes()
+    t0 = time.perf_counter()
+    table = cpu_ref.count_text(data, k, c)
+    return reads * READ_LEN, time.perf_counter() - t0, len(table)
+
+
+def cpu_baseline(k, c):
+    """Bounded CPU run of the oracle: P processes, each one chunk of 40k reads at ~150x coverage
+    (the cache-friendliest case for the dict, i.e. generous to the CPU)."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    reads = 40_000
+    rounds = 2
+    jobs = [(i, reads, k, c) for i in range(cores * rounds)]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(cpu_sample_worker, jobs)
+    wall = time.perf_counter() - t0
+    bases = sum(r[0] for r in res)
+    busy = sum(r[1] for r in res)
+    return {"value": bases / wall, "unit": "bases/s", "cores": cores, "kind": "port",
+            "sample": "%d chunks x %d reads x %d bp (genome %d bp per chunk, ~150x), k=%d, c=%d, pure-Python oracle, "
+                      "%d processes; per-core rate %.3g bases/s" % (len(jobs), reads, READ_LEN, reads, k, c, cores,
+                                                                    bases / busy)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=READS, help="reads per rank (default: the BASELINE workload)")
+    ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mercat2_amd import native
+    from mercat2_amd.chunker import chunk_offsets
+    from mercat2_amd.dist import merge_ranks
+
+    # ---- synthetic input: generate on the host, cut like the reference Chunker, move to HBM
+    k = args.k
+    t0 = time.perf_counter()
+    host = native.synth_reads(GENOME, GENOME_SEED, args.reads, READ_LEN, READ_SEED, 0, rank * args.reads)
+    offs = chunk_offsets(host, CHUNK_MIB * 1024 * 1024) if host.nbytes >= CHUNK_MIB * 1024 * 1024 else [0, host.nbytes]
+    text = torch.from_numpy(host).to(dev)
+    gen_s = time.perf_counter() - t0
+    del host
+    bases_rank = args.reads * READ_LEN
+    windows_rank = args.reads * (READ_LEN - k + 1)
+
+    ctx = native.Counter(k, native.ALPHABET_NT2, device=local)
+    key_bits = 2 * k
+    out_cap = 2 * GENOME + 1024  # distinct forward-strand k-mers of both strands, upper bound
+    out_keys = torch.empty(out_cap, dtype=torch.int64, device=dev)
+    out_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev)
+    base_ptr = text.data_ptr()
+
+    def step():
+        ctx.reset()
+        for a, b in zip(offs[:-1], offs[1:]):
+            ctx.count_device(base_ptr + a, b - a, MIN_COUNT)
+        if world > 1:
+            merge_ranks(ctx, key_bits, device=dev)
+        return ctx.export_pairs_device(out_keys.data_ptr(), out_cnts.data_ptr(), out_cap)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_stats()
+    ctx.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    rows = 0
+    for _ in range(args.steps):
+        rows = step()
+    fence()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    ctx.set_profiling(False)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    r = torch.tensor([rows], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    total_rows = int(r.item())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = bases_rank * world * args.steps / dt
+        launches = max(1, st["n_count"])
+        ms_launch = st["ms_count"] / launches
+        alg_bytes = (st["windows"] - st["exotic_windows"]) * 16 + st["symbols"] * 0.25  # over all timed launches
+        achieved = alg_bytes / launches / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        line = {
+            "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "S2: %d reads x %d bp per GPU from a %d bp genome, k=%d, -c %d, -s %d (%d chunks), "
+                                   "forward-strand keys" % (args.reads, READ_LEN, GENOME, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1),
+                       "reads_per_gpu": args.reads, "read_len": READ_LEN, "k": k, "min_count": MIN_COUNT,
+                       "chunk_mib": CHUNK_MIB, "chunks": len(offs) - 1, "mode": st["mode_name"],
+                       "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
+            "distinct_kmers_per_s": total_rows * args.steps / dt,
+            "rows": total_rows,
+            "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "count", "exotic", "filter", "export")},
+            "roofline": {"bound": "hbm", "kernel": "mk_count_hash64_k", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "launches": launches, "ms_per_launch": ms_launch,
+                         "algorithmic_bytes_per_launch": alg_bytes / launches},
+            "input_gen_s": gen_s,
+        }
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(k, MIN_COUNT)
+            line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -82,24 +82,29 @@ extern "C" int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_
   *written = total;
   if (!out) return MK_OK;
   if (cap < total) return MK_ERR_RANGE;
-  // genome: 2-bit codes, 32 bases per splitmix64 draw (base j of a draw = bits 2j..2j+1)
-  std::vector<uint8_t> g(genome_len);
+  // genome as ASCII, forward and reverse-complement (rc[i] = complement(fwd[G-1-i])), so that a
+  // read is one memcpy. 32 bases per splitmix64 draw (base j of a draw = bits 2j..2j+1).
+  static const char L[4] = {'A', 'C', 'G', 'T'};
+  std::vector<uint8_t> fwd(genome_len), rc(genome_len);
   {
     uint64_t s = genome_seed;
     for (uint64_t i = 0; i < genome_len; i += 32) {
       uint64_t r = splitmix64(s);
       uint64_t m = genome_len - i < 32 ? genome_len - i : 32;
-      for (uint64_t j = 0; j < m; ++j) g[i + j] = (uint8_t)((r >> (2 * j)) & 3);
+      for (uint64_t j = 0; j < m; ++j) {
+        unsigned code = (unsigned)((r >> (2 * j)) & 3);
+        fwd[i + j] = (uint8_t)L[code];
+        rc[genome_len - 1 - (i + j)] = (uint8_t)L[3 - code];
+      }
     }
   }
-  static const char L[4] = {'A', 'C', 'G', 'T'};
   uint8_t* w = out;
   const uint64_t span = genome_len - read_len + 1;
   for (uint64_t r = 0; r < reads; ++r) {
     const uint64_t idx = first_index + r;
     uint64_t s = read_seed + idx * 0x632BE59BD9B4E019ull;
     const uint64_t start = splitmix64(s) % span;
-    const bool rc = (splitmix64(s) >> 63) != 0;
+    const bool is_rc = (splitmix64(s) >> 63) != 0;
     *w++ = '>';
     *w++ = 'r';
     char num[24];
@@ -108,14 +113,19 @@ extern "C" int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_
     do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
     while (len) *w++ = (uint8_t)num[--len];
     *w++ = '\n';
-    for (uint32_t j = 0; j < read_len; ++j) {
-      unsigned b = rc ? (3u - g[start + read_len - 1 - j]) : g[start + j];
-      if (sub_ppm) {
+    // reverse strand: revcomp(fwd[start .. start+L)) == rc[G-start-L .. G-start)
+    const uint8_t* src = is_rc ? rc.data() + (genome_len - start - read_len) : fwd.data() + start;
+    memcpy(w, src, read_len);
+    if (sub_ppm) {
+      for (uint32_t j = 0; j < read_len; ++j) {
         uint64_t d = splitmix64(s);
-        if (d % 1000000ull < sub_ppm) b = (b + 1 + (unsigned)((d >> 32) % 3)) & 3u;
+        if (d % 1000000ull < sub_ppm) {
+          unsigned b = w[j] == 'A' ? 0 : (w[j] == 'C' ? 1 : (w[j] == 'G' ? 2 : 3));
+          w[j] = (uint8_t)L[(b + 1 + (unsigned)((d >> 32) % 3)) & 3u];
+        }
       }
-      *w++ = (uint8_t)L[b];
     }
+    w += read_len;
     *w++ = '\n';
   }
   return MK_OK;

@@ -1,0 +1,91 @@
+"""Multi-GPU merge of per-rank count tables (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Replaces the reference's cross-worker merge -- ``ray.get`` of every chunk's dict and the dict
+sum in run_mercat2 (bin/mercat2.py:121-127).  Chunks are dealt to ranks round-robin; every rank
+filters its own chunks (the per-chunk min_count rule) and accumulates the survivors into its
+running table.  The only exchange step is this one: rows are re-partitioned by KEY RANGE
+(owner = floor(key * world / 2^bits)), sent with one all_to_all per array straight between
+peers (each pair of GPUs has its own xGMI link, so all 7 links carry traffic at once; no ring),
+and insert-added at the owner.  Each owner then holds a contiguous, sorted key range, so the
+globally sorted table is the concatenation of the ranks' exports in rank order.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+_SIGN = -(1 << 63)
+
+
+def _ordered(keys: torch.Tensor) -> torch.Tensor:
+    """uint64 keys stored in int64 tensors: flip the sign bit so signed order == unsigned order."""
+    return keys ^ _SIGN
+
+
+def range_bounds(key_bits: int, world: int) -> List[int]:
+    """First key owned by rank 1..world-1 when [0, 2^key_bits) is cut into `world` equal ranges."""
+    return [((i << key_bits) + world - 1) // world for i in range(1, world)]
+
+
+def split_points(sorted_keys: torch.Tensor, key_bits: int, world: int) -> torch.Tensor:
+    """Index of the first row of every rank's range in an ascending (unsigned) key tensor."""
+    b = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in range_bounds(key_bits, world)],
+                     dtype=torch.int64, device=sorted_keys.device)
+    cut = torch.searchsorted(_ordered(sorted_keys), _ordered(b), right=False)
+    zero = torch.zeros(1, dtype=cut.dtype, device=cut.device)
+    end = torch.full((1,), sorted_keys.numel(), dtype=cut.dtype, device=cut.device)
+    return torch.cat([zero, cut, end])
+
+
+def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All-to-all of (key, count) rows by key range.  `keys` ascending (unsigned), int64 storage.
+    Returns the rows this rank owns (concatenation of what every peer sent, peer order)."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return keys, counts
+    pts = split_points(keys, key_bits, world)
+    send = (pts[1:] - pts[:-1]).to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    send_l, recv_l = send.tolist(), recv.tolist()
+    out_k = torch.empty(int(sum(recv_l)), dtype=keys.dtype, device=keys.device)
+    out_c = torch.empty_like(out_k)
+    dist.all_to_all_single(out_k, keys, recv_l, send_l, group=group)
+    dist.all_to_all_single(out_c, counts, recv_l, send_l, group=group)
+    return out_k, out_c
+
+
+def merge_ranks(ctx, key_bits: int, group=None, device=None) -> int:
+    """Re-partition ctx's running table across the ranks of `group` by key range and sum.
+    On return ctx holds exactly the rows of its own range (by-reference rows: all on rank 0).
+    Returns the number of rows this rank now owns."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return ctx.rows()
+    dev = device if device is not None else torch.device("cuda", ctx.device)
+    st = ctx.stats()
+    packed = st["mode_name"] != "byref"
+    if packed:
+        cap = ctx.rows() + 1
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnts = torch.empty(cap, dtype=torch.int64, device=dev)
+        n = ctx.export_pairs_device(keys.data_ptr(), cnts.data_ptr(), cap)
+        keys, cnts = keys[:n], cnts[:n]
+    ex_k, ex_c = ctx.export_exotic()
+    ctx.reset()
+    if packed:
+        rk, rc = exchange_pairs(keys, cnts, key_bits, group)
+        if rk.numel():
+            torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+            ctx.import_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (ex_k, ex_c), group=group)
+    if rank == 0:
+        for k_arr, c_arr in gathered:
+            ctx.import_exotic(k_arr, c_arr)
+    return ctx.rows()

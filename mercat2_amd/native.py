@@ -114,6 +114,15 @@ def _buf_ptr(data) -> Tuple[int, int, object]:
     return a.ctypes.data, a.nbytes, a
 
 
+def _big_u8(n: int) -> np.ndarray:
+    """Writable uint8 buffer from an anonymous mmap.  (np.empty madvises huge pages for large
+    blocks, which makes the first touch of every page very slow in some sandboxes.)"""
+    import mmap
+    if n == 0:
+        return np.empty(0, dtype=np.uint8)
+    return np.frombuffer(mmap.mmap(-1, n), dtype=np.uint8)
+
+
 # ------------------------------------------------------------------------------ host helpers
 def chunk_cuts(text, chunksize: int) -> np.ndarray:
     """Offsets at which the reference Chunker would start chunks 1.. (lib/mercat2_Chunker.py:39-59)."""
@@ -139,7 +148,7 @@ def synth_reads(genome_len: int, genome_seed: int, reads: int, read_len: int, re
     rc = L.mk_synth_reads(genome_len, genome_seed, reads, read_len, read_seed, sub_ppm, first_index, None, 0, C.byref(size))
     if rc:
         raise MercatHipError(rc, "mk_synth_reads(size)")
-    out = np.empty(size.value, dtype=np.uint8)
+    out = _big_u8(size.value)
     rc = L.mk_synth_reads(genome_len, genome_seed, reads, read_len, read_seed, sub_ppm, first_index,
                           out.ctypes.data, out.nbytes, C.byref(size))
     if rc:
