@@ -7,6 +7,7 @@
 #include "mk_common.h"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -137,6 +138,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   const long kb = (long)k * c->bits;
   c->mode = (c->bits == 0) ? MK_MODE_BYREF : (kb <= 15 ? MK_MODE_DENSE : (kb <= 64 ? MK_MODE_HASH64 : MK_MODE_BYREF));
   c->st.mode = c->mode;
+  c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {
     g_err = msg;
@@ -170,7 +172,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
-                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp};
+                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -291,7 +293,9 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
 
   // chunk tables
   c->rtab_chunk_slots = 0;
-  if (c->mode == MK_MODE_HASH64) {
+  const bool partitioned = c->mode == MK_MODE_HASH64 && c->use_partition;
+  c->ctab_slots = c->mode == MK_MODE_DENSE ? c->ctab_slots : 0;
+  if (c->mode == MK_MODE_HASH64 && !partitioned) {
     c->ctab_slots = pow2_at_least(2 * seq_len);
     if ((rc = mk_buf_reserve(c, c->ctab, c->ctab_slots * sizeof(MkSlot))) != MK_OK) return rc;
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
@@ -310,6 +314,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
 
   // count
   if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
+  else if (partitioned) rc = mk_launch_count_partitioned(c, seq_len, min_count);
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
   if (rc) return rc;
   if (c->rtab_chunk_slots && (rc = mk_launch_count_byref(c, seq_len, packed)) != MK_OK) return rc;
@@ -317,15 +322,26 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   // filter (per chunk!) + merge
   if ((rc = mk_launch_count_survivors(c, min_count)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
+  if (c->h_info->errors) {
+    c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";
+    return MK_ERR_RANGE;
+  }
   if (c->mode == MK_MODE_HASH64 && c->h_info->survivors)
     if ((rc = grow_run64(c, c->run_rows + (size_t)c->h_info->survivors)) != MK_OK) return rc;
   if (c->h_info->survivors_ref)
     if ((rc = grow_run_ref(c, c->run_ref_rows + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
+  if (partitioned && c->h_info->survivors) {
+    mk_prof_begin(c, MK_K_FILTER);
+    rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors);
+    mk_prof_end(c);
+    if (rc) return rc;
+  }
   if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
   c->run_rows += (size_t)c->h_info->new_rows;
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
+  if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
 
   c->st.raw_bytes += n;
   c->st.symbols += c->h_info->symbols;

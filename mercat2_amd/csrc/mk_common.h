@@ -50,7 +50,9 @@ struct MkChunkInfo {
   unsigned long long side;          // count of the one key that equals MK_EMPTY (all-T 32-mer)
   unsigned long long new_rows;      // rows added to the running table by this chunk
   unsigned long long new_rows_ref;
-  unsigned long long pad[5];
+  unsigned long long distinct;      // distinct packed keys seen in this chunk (partitioned path)
+  unsigned long long errors;        // non-zero: a kernel hit a condition it cannot handle
+  unsigned long long pad[3];
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
@@ -120,6 +122,14 @@ struct mk_ctx {
   MkDevBuf arena;       // k bytes per by-reference row
   size_t arena_rows_cap = 0;
 
+  // partitioned counting (hash64): keys bucketed by hash, counted per bucket in LDS
+  MkDevBuf part;        // u64 keys, bucket after bucket
+  MkDevBuf part_meta;   // u64 hist[P1] | start[P1+1] | cursor[P1]
+  MkDevBuf surv_keys, surv_cnts;  // (key,count) survivors of the chunk
+  int p1_log2 = 10;
+  double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
+  int use_partition = 1;
+
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
 
@@ -147,6 +157,8 @@ int mk_launch_pack(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_dense(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_hash64(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_byref(mk_ctx* c, size_t seq_cap, bool exotic_only);
+// partitioned hash64 path: windows -> hash buckets -> per-bucket LDS tables -> survivors (count >= min_count)
+int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // tables
 int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
 int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);

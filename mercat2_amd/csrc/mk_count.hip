@@ -15,26 +15,7 @@
 //           the union is the reference's "any character" semantics.
 // A window is counted iff it lies inside one record (no separator) -- lib/mercat2_kmers.py:52-61.
 #include "mk_common.h"
-
-typedef unsigned long long u64;
-
-// ------------------------------------------------------------------------ packed windows
-// Key of the k symbols that start at symbol s (static) of `cur`, continuing into `nxt`.
-template <int BITS, int SPW>
-__device__ __forceinline__ u64 window_key(u64 cur, u64 nxt, int s, int k) {
-  u64 key = (cur << (BITS * s)) >> (64 - BITS * k);
-  const int over = s + k - SPW;  // symbols taken from the next word
-  if (over > 0) key |= nxt >> (64 - BITS * over);
-  return key;
-}
-
-__device__ __forceinline__ u64 bad_window(const u64* __restrict__ bad, size_t p0) {
-  const size_t bi = p0 >> 6;
-  const int bo = (int)(p0 & 63);
-  const u64 b0 = bad[bi];
-  if (bo == 0) return b0;
-  return (b0 >> bo) | (bad[bi + 1] << (64 - bo));
-}
+#include "mk_device.h"
 
 __device__ __forceinline__ void add_windows(MkChunkInfo* info, unsigned mine, bool exotic) {
   for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
