@@ -139,6 +139,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->mode = (c->bits == 0) ? MK_MODE_BYREF : (kb <= 15 ? MK_MODE_DENSE : (kb <= 64 ? MK_MODE_HASH64 : MK_MODE_BYREF));
   c->st.mode = c->mode;
   c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
+  c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {
     g_err = msg;
@@ -273,16 +274,22 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   MK_HIP(hipSetDevice(c->device));
   MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
   if ((rc = mk_buf_reserve(c, c->seq, n + 256)) != MK_OK) return rc;
-  if ((rc = mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
   const bool packed = c->mode != MK_MODE_BYREF;
+  const size_t bad_words = n / 64 + 4;
+  const size_t code_words = c->alphabet == MK_ALPHABET_NT2 ? 2 * bad_words : (bad_words * 64 + 11) / 12;
   if (packed) {
-    const size_t bad_words = n / 64 + 4;
-    const size_t code_words = c->alphabet == MK_ALPHABET_NT2 ? 2 * bad_words : (bad_words * 64 + 11) / 12;
     if ((rc = mk_buf_reserve(c, c->bad, (bad_words + 2) * 8)) != MK_OK) return rc;
     if ((rc = mk_buf_reserve(c, c->codes, (code_words + 8) * 8)) != MK_OK) return rc;
-    if ((rc = mk_launch_pack(c, n)) != MK_OK) return rc;
   }
-  if ((rc = pull_info(c)) != MK_OK) return rc;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const bool fast = c->use_fast_parse && attempt == 0;
+    if ((rc = fast ? mk_launch_fparse(c, d_raw, n) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
+    if (packed && (rc = mk_launch_pack(c, n)) != MK_OK) return rc;
+    if ((rc = pull_info(c)) != MK_OK) return rc;
+    if (!fast || !c->h_info->parse_fallback) break;
+    // a blank inside a sequence line: the general transducer handles strip() exactly
+    MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  }
   if (c->h_info->non_ascii) {
     c->err = "input holds " + std::to_string(c->h_info->non_ascii) +
              " byte(s) >= 0x80 (non-ASCII text is not supported; the chunk was not counted)";

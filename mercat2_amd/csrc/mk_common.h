@@ -52,7 +52,8 @@ struct MkChunkInfo {
   unsigned long long new_rows_ref;
   unsigned long long distinct;      // distinct packed keys seen in this chunk (partitioned path)
   unsigned long long errors;        // non-zero: a kernel hit a condition it cannot handle
-  unsigned long long pad[3];
+  unsigned long long parse_fallback;  // fast parser saw a blank in a sequence line: re-parse generally
+  unsigned long long pad[2];
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
@@ -129,6 +130,7 @@ struct mk_ctx {
   int p1_log2 = 10;
   double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
   int use_partition = 1;
+  int use_fast_parse = 1;
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
@@ -151,6 +153,8 @@ struct mk_ctx {
 // ---- kernel launchers (each in its own translation unit) ---------------------------------
 // parse: raw[n] -> seq, info (seq_len, symbols, non_ascii)
 int mk_launch_parse(mk_ctx* c, const uint8_t* d_raw, size_t n);
+// fast parse (mk_fparse.hip): same output; sets info.parse_fallback when its assumption fails
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n);
 // pack: seq -> codes, bad (+ info.bad_symbols)
 int mk_launch_pack(mk_ctx* c, size_t seq_cap);
 // counting

@@ -1,0 +1,314 @@
+// mk_fparse.hip -- fast FASTA parser for the common shape of input; the general transducer of
+// mk_parse.hip stays the reference for everything else.
+//
+// Same contract as mk_parse.hip (reference loop lib/mercat2_kmers.py:49-69): raw bytes -> seq
+// (kept characters, one MK_SEP where a header line starts).  The fast form assumes ONE thing:
+// no byte <= 0x20 other than '\n' / '\r' occurs in a line that does not start with '>'.  Under
+// that assumption strip() has nothing to trim in sequence lines and a line is a header iff its
+// first byte is '>'.  The kernels check the assumption on every byte; when it fails they raise
+// info->parse_fallback and the host re-parses the chunk with the general kernels (exact for any
+// input).  Blanks inside header lines (">r1 some description") are the normal case and fine.
+//
+// Bit-parallel formulation.  Every lane owns 16 consecutive bytes (one 16-byte load) and turns
+// them into 16-bit class masks (NL, '>', '*', low).  "Inside a header line" is the recurrence
+//      H[j] = start[j] | (~NL[j] & H[j-1])
+// which is exactly a carry chain: with a = start|~NL and b = start, the carries of a+b are H.
+// One 32-bit add resolves it inside a lane, one 64-bit add over the wave's ballots resolves it
+// across the 64 lanes (1 KiB), and the state between waves is a 2-state map scanned by
+// mk_fparse_scan -- no per-byte branching anywhere.
+//   pass 1 mk_fparse_summ  per wave (4 KiB): {has newline, exit state, bytes emitted for entry 0 / 1}
+//   pass 2 mk_fparse_scan  exclusive scan of those maps -> entry state + output offset per wave
+//   pass 3 mk_fparse_emit  recompute masks, compact the kept bytes into LDS at the alignment of
+//                          their destination, write them out with aligned 16-byte stores
+#include "mk_common.h"
+
+typedef unsigned long long u64;
+
+#define FP_THREADS 256
+#define FP_SUB 4                       // 1 KiB sub-steps per wave
+#define FP_WAVE_BYTES (FP_SUB * 1024)  // input bytes per wave
+#define FP_WAVES (FP_THREADS / 64)
+
+struct FpEntry {  // per wave summary / scan result
+  unsigned a;     // summ: bit0 has_nl, bit1 exit0 ; scan: entry state
+  unsigned b;     // summ: cnt0 | cnt1 << 16
+};
+
+// Class masks of 16 bytes. Bytes at or beyond `n` behave like newlines (they emit nothing).
+__device__ __forceinline__ void classify16(const uint8_t* __restrict__ raw, size_t pos, size_t n, uint4& v, unsigned& nl,
+                                           unsigned& gt, unsigned& st, unsigned& low, unsigned& hi) {
+  if (pos + 16 <= n) {
+    v = *reinterpret_cast<const uint4*>(raw + pos);
+  } else {
+    unsigned w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
+    for (int j = 0; j < 16; ++j)
+      if (pos + j < n) w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((unsigned)raw[pos + j] << (8 * (j & 3)));
+    v = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  const unsigned x[4] = {v.x, v.y, v.z, v.w};
+  nl = gt = st = low = 0;
+  hi = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    hi += __popc(x[d] & 0x80808080u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned c = (x[d] >> (8 * e)) & 0xFFu;
+      const unsigned bit = 1u << (d * 4 + e);
+      const bool is_nl = (c == 10u) | (c == 13u);
+      if (is_nl) nl |= bit;
+      if (c == 62u) gt |= bit;
+      if (c == 42u) st |= bit;
+      if (c <= 32u && !is_nl) low |= bit;
+    }
+  }
+}
+
+// Header mask of one lane given its entry state: carries of (start|~NL) + start + hin.
+__device__ __forceinline__ unsigned lane_header(unsigned start, unsigned nl, unsigned hin, unsigned& hout) {
+  const unsigned p = ~nl & 0xFFFFu;
+  const unsigned a = start | p, b = start;
+  const unsigned sum = a + b + hin;
+  const unsigned ci = sum ^ a ^ b;  // bit j = carry into bit j ; bit j+1 = H[j]
+  hout = (ci >> 16) & 1u;
+  return (ci >> 1) & 0xFFFFu;
+}
+
+// One 1 KiB sub-step of a wave. In: class masks of this lane, prev_nl (previous byte of the
+// stream is a newline, or start of chunk) and cin (stream is inside a header line).
+// Out: `out` mask of emitted bytes, `sep` mask (emitted bytes that are separators), flags;
+// returns the wave's exit header state; *last_nl = last byte of the sub-step is a newline.
+__device__ __forceinline__ unsigned wave_step(unsigned nl, unsigned gt, unsigned st, unsigned low, unsigned prev_nl,
+                                              unsigned cin, unsigned& out, unsigned& sep, unsigned& bad_low,
+                                              unsigned& last_nl) {
+  const int lane = threadIdx.x & 63;
+  const unsigned my_last_nl = (nl >> 15) & 1u;
+  unsigned prev = __shfl_up(my_last_nl, 1);
+  if (lane == 0) prev = prev_nl;
+  const unsigned ls = ((nl << 1) | prev) & 0xFFFFu;  // line-start bits
+  const unsigned start = ls & gt;                    // '>' at a line start
+  unsigned hout0;
+  (void)lane_header(start, nl, 0u, hout0);
+  const u64 G = __ballot(hout0 != 0);        // lane ends inside a header whatever its entry
+  const u64 P = __ballot(nl == 0);           // lane has no newline: passes its entry state on
+  const u64 A = G | P, B = G;
+  const u64 sum = A + B + (u64)cin;
+  const u64 CI = sum ^ A ^ B;                // bit l = header state entering lane l
+  const unsigned hin = (unsigned)(CI >> lane) & 1u;
+  unsigned hout;
+  const unsigned H = lane_header(start, nl, hin, hout);
+  sep = start;
+  out = ((~H & ~nl & ~st) | start) & 0xFFFFu;
+  bad_low = low & ~H;
+  last_nl = __shfl(my_last_nl, 63);
+  return __shfl(hout, 63);
+}
+
+__global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __restrict__ raw, size_t n, size_t nwaves,
+                                                             FpEntry* __restrict__ entries, MkChunkInfo* __restrict__ info) {
+  const size_t wave = (size_t)blockIdx.x * FP_WAVES + (threadIdx.x >> 6);
+  if (wave >= nwaves) return;
+  const int lane = threadIdx.x & 63;
+  const size_t base = wave * FP_WAVE_BYTES;
+  unsigned prev_nl = (base == 0) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
+  unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0, nhi = 0;
+#pragma unroll 1
+  for (int sub = 0; sub < FP_SUB; ++sub) {
+    const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
+    uint4 v;
+    unsigned nl, gt, st, low, hi;
+    classify16(raw, pos, n, v, nl, gt, st, low, hi);
+    nhi += hi;
+    unsigned out, sep, bl, last_nl;
+    const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
+    c0 += __popc(out);
+    flag_low |= bl;
+    if (s1 != s0) {
+      unsigned out1, sep1, bl1, ln1;
+      const unsigned e1 = wave_step(nl, gt, st, low, prev_nl, s1, out1, sep1, bl1, ln1);
+      c1 += __popc(out1);
+      flag_low |= bl1;
+      s1 = e1;
+    } else {
+      c1 += __popc(out);
+      s1 = e0;
+    }
+    s0 = e0;
+    any_nl |= (__ballot(nl != 0) != 0) ? 1u : 0u;
+    prev_nl = last_nl;
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    c0 += __shfl_down(c0, d);
+    c1 += __shfl_down(c1, d);
+    nhi += __shfl_down(nhi, d);
+  }
+  const bool any_low = __ballot(flag_low != 0) != 0;
+  if (lane == 0) {
+    entries[wave].a = any_nl | (s0 << 1);
+    entries[wave].b = c0 | (c1 << 16);
+    if (any_low) atomicOr(&info->parse_fallback, 1ull);
+    if (nhi) atomicAdd(&info->non_ascii, (u64)nhi);
+  }
+}
+
+struct FpScan {
+  u64 off;
+  unsigned st;
+  unsigned pad;
+};
+
+// One workgroup: thread t owns waves [t*per, (t+1)*per). A wave without a newline passes its
+// entry state through (or-ed with its own exit0); one with a newline resets it to exit0.
+__global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict__ entries, size_t nwaves,
+                                                       FpScan* __restrict__ scan, MkChunkInfo* __restrict__ info) {
+  __shared__ unsigned char t_nl[1024], t_e0[1024], t_e1[1024];
+  __shared__ u64 t_c0[1024], t_c1[1024];
+  __shared__ unsigned char in_st[1025];
+  __shared__ u64 in_off[1025];
+  const size_t per = (nwaves + 1023) / 1024;
+  const size_t lo = (size_t)threadIdx.x * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
+  unsigned e0 = 0, e1 = 1, has = 0;  // running map of this thread's range
+  u64 c0 = 0, c1 = 0;
+  for (size_t w = lo; w < hi; ++w) {
+    const FpEntry en = entries[w];
+    const unsigned wnl = en.a & 1u, wx0 = (en.a >> 1) & 1u;
+    const unsigned k0 = en.b & 0xFFFFu, k1 = en.b >> 16;
+    c0 += e0 ? k1 : k0;
+    c1 += e1 ? k1 : k0;
+    e0 = wnl ? wx0 : (e0 | wx0);
+    e1 = wnl ? wx0 : (e1 | wx0);
+    has |= wnl;
+  }
+  t_nl[threadIdx.x] = (unsigned char)has;
+  t_e0[threadIdx.x] = (unsigned char)e0;
+  t_e1[threadIdx.x] = (unsigned char)e1;
+  t_c0[threadIdx.x] = c0;
+  t_c1[threadIdx.x] = c1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned q = 0;  // the chunk starts outside any header
+    u64 off = 0;
+    for (int t = 0; t < 1024; ++t) {
+      in_st[t] = (unsigned char)q;
+      in_off[t] = off;
+      off += q ? t_c1[t] : t_c0[t];
+      q = q ? t_e1[t] : t_e0[t];
+    }
+    info->seq_len = off;
+  }
+  __syncthreads();
+  unsigned q = in_st[threadIdx.x];
+  u64 off = in_off[threadIdx.x];
+  for (size_t w = lo; w < hi; ++w) {
+    const FpEntry en = entries[w];
+    scan[w].off = off;
+    scan[w].st = q;
+    const unsigned wnl = en.a & 1u, wx0 = (en.a >> 1) & 1u;
+    off += q ? (en.b >> 16) : (en.b & 0xFFFFu);
+    q = wnl ? wx0 : (q | wx0);
+  }
+}
+
+__global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __restrict__ raw, size_t n, size_t nwaves,
+                                                             FpScan* __restrict__ scan, uint8_t* __restrict__ seq,
+                                                             MkChunkInfo* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][FP_WAVE_BYTES + 32];
+  const int wv = threadIdx.x >> 6;
+  const size_t wave = (size_t)blockIdx.x * FP_WAVES + wv;
+  if (wave >= nwaves) return;
+  const int lane = threadIdx.x & 63;
+  const size_t base = wave * FP_WAVE_BYTES;
+  const FpScan sc = scan[wave];
+  const unsigned shift = (unsigned)(sc.off & 15);
+  uint8_t* __restrict__ lds = stage[wv];
+  unsigned prev_nl = (base == 0) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
+  unsigned state = sc.st;
+  unsigned filled = 0;   // bytes emitted so far by this wave
+  unsigned nsym = 0;
+#pragma unroll 1
+  for (int sub = 0; sub < FP_SUB; ++sub) {
+    const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
+    uint4 v;
+    unsigned nl, gt, st, low, hi;
+    classify16(raw, pos, n, v, nl, gt, st, low, hi);
+    unsigned out, sep, bl, last_nl;
+    state = wave_step(nl, gt, st, low, prev_nl, state, out, sep, bl, last_nl);
+    prev_nl = last_nl;
+    const unsigned cnt = __popc(out);
+    nsym += cnt - __popc(sep);
+    unsigned inc = cnt;  // inclusive scan over the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned up = __shfl_up(inc, d);
+      if (lane >= d) inc += up;
+    }
+    unsigned at = shift + filled + inc - cnt;
+    const unsigned x[4] = {v.x, v.y, v.z, v.w};
+    if (out == 0xFFFFu && sep == 0) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lds[at + j] = (uint8_t)(x[j >> 2] >> (8 * (j & 3)));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if ((out >> j) & 1u) {
+          lds[at] = ((sep >> j) & 1u) ? (uint8_t)MK_SEP : (uint8_t)(x[j >> 2] >> (8 * (j & 3)));
+          ++at;
+        }
+      }
+    }
+    filled += __shfl(inc, 63);
+  }
+  // ---- write out: LDS offset == destination address (mod 16), so full 16-byte pieces are aligned
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  uint8_t* __restrict__ dst = seq + (sc.off - shift);
+  const unsigned end = shift + filled;
+  for (unsigned c = (unsigned)lane * 16; c < end; c += 64 * 16) {
+    if (c >= shift && c + 16 <= end) {
+      *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(lds + c);
+    } else {
+      const unsigned lo = c < shift ? shift : c;
+      const unsigned hi = c + 16 < end ? c + 16 : end;
+      for (unsigned j = lo; j < hi; ++j) dst[j] = lds[j];
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) nsym += __shfl_down(nsym, d);
+  if (lane == 0) scan[wave].pad = nsym;  // summed by mk_fparse_total (no hot atomic)
+}
+
+__global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict__ scan, size_t nwaves,
+                                                        MkChunkInfo* __restrict__ info) {
+  __shared__ u64 part[16];
+  u64 s = 0;
+  for (size_t w = threadIdx.x; w < nwaves; w += 1024) s += scan[w].pad;
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t = 0;
+    for (int i = 0; i < 16; ++i) t += part[i];
+    info->symbols = t;
+  }
+}
+
+// Returns MK_OK after enqueueing; info->parse_fallback != 0 afterwards means "re-parse with the general kernels".
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n) {
+  if (n == 0) return MK_OK;
+  const size_t nwaves = (n + FP_WAVE_BYTES - 1) / FP_WAVE_BYTES;
+  const size_t e_bytes = (nwaves * sizeof(FpEntry) + 15) & ~(size_t)15;
+  int rc = mk_buf_reserve(c, c->tile_maps, e_bytes + nwaves * sizeof(FpScan));
+  if (rc) return rc;
+  FpEntry* entries = (FpEntry*)c->tile_maps.p;
+  FpScan* scan = (FpScan*)((char*)c->tile_maps.p + e_bytes);
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const unsigned blocks = (unsigned)((nwaves + FP_WAVES - 1) / FP_WAVES);
+  mk_prof_begin(c, MK_K_PARSE);
+  hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, entries, info);
+  hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info);
+  hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, scan,
+                     (uint8_t*)c->seq.p, info);
+  hipLaunchKernelGGL(mk_fparse_total, dim3(1), dim3(1024), 0, c->stream, (const FpScan*)scan, nwaves, info);
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}

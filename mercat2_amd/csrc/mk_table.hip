@@ -285,11 +285,21 @@ int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_co
 // Occupied slots of a table -> (keys, counts) in arbitrary order; *cursor counts them.
 __global__ void mk_compact_k(const MkSlot* __restrict__ t, size_t slots, u64* __restrict__ keys, u64* __restrict__ cnts,
                              size_t cap, u64* __restrict__ cursor) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
-    ulonglong2 s = reinterpret_cast<const ulonglong2*>(t)[i];
-    if (s.x != MK_EMPTY && s.y != 0) {
-      u64 at = atomicAdd(cursor, 1ull);
-      if (at < cap) { keys[at] = s.x; cnts[at] = s.y; }
+  // grid-stride with a wave-uniform trip count so that the ballot below sees whole waves
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t rounds = (slots + stride - 1) / stride;
+  const int lane = threadIdx.x & 63;
+  for (size_t r = 0; r < rounds; ++r) {
+    const size_t i = r * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ulonglong2 s = make_ulonglong2(MK_EMPTY, 0);
+    if (i < slots) s = reinterpret_cast<const ulonglong2*>(t)[i];
+    const bool keep = s.x != MK_EMPTY && s.y != 0;
+    const u64 m = __ballot(keep);
+    if (m) {  // one cursor atomic per wave, not per row
+      u64 at = 0;
+      if (lane == 0) at = atomicAdd(cursor, (u64)__popcll(m));
+      at = __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1));
+      if (keep && at < cap) { keys[at] = s.x; cnts[at] = s.y; }
     }
   }
 }
