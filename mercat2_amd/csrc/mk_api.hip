@@ -140,6 +140,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->st.mode = c->mode;
   c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
+  c->use_superkmer = getenv("MK_NO_SUPERKMER") ? 0 : 1;
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {
     g_err = msg;
@@ -301,6 +302,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   // chunk tables
   c->rtab_chunk_slots = 0;
   const bool partitioned = c->mode == MK_MODE_HASH64 && c->use_partition;
+  c->surv_regions = 0;
   c->ctab_slots = c->mode == MK_MODE_DENSE ? c->ctab_slots : 0;
   if (c->mode == MK_MODE_HASH64 && !partitioned) {
     c->ctab_slots = pow2_at_least(2 * seq_len);
@@ -321,7 +323,10 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
 
   // count
   if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
-  else if (partitioned) rc = mk_launch_count_partitioned(c, seq_len, min_count);
+  else if (partitioned) {
+    const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= 18 && c->k <= 32;
+    rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
+  }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
   if (rc) return rc;
   if (c->rtab_chunk_slots && (rc = mk_launch_count_byref(c, seq_len, packed)) != MK_OK) return rc;
@@ -339,7 +344,14 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = grow_run_ref(c, c->run_ref_rows + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
   if (partitioned && c->h_info->survivors) {
     mk_prof_begin(c, MK_K_FILTER);
-    rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors);
+    if (c->surv_regions) {
+      const size_t p1 = (size_t)1 << c->p1_log2;
+      const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
+      rc = mk_launch_import_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p,
+                                    meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+    } else {
+      rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors);
+    }
     mk_prof_end(c);
     if (rc) return rc;
   }
@@ -349,7 +361,12 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
   if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
+  if (partitioned && c->h_info->records) c->nk_hint = (double)c->h_info->windows / (double)c->h_info->records;
 
+  if (getenv("MK_VERBOSE"))
+    fprintf(stderr, "[mk] chunk: raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu new_rows=%llu p1=2^%d dup=%.2f nk=%.2f\n", n, seq_len,
+            (unsigned long long)c->h_info->windows, (unsigned long long)c->h_info->records, (unsigned long long)c->h_info->distinct,
+            (unsigned long long)c->h_info->survivors, (unsigned long long)c->h_info->new_rows, c->p1_log2, c->dup_hint, c->nk_hint);
   c->st.raw_bytes += n;
   c->st.symbols += c->h_info->symbols;
   c->st.windows += c->h_info->windows + c->h_info->exotic;

@@ -53,7 +53,8 @@ struct MkChunkInfo {
   unsigned long long distinct;      // distinct packed keys seen in this chunk (partitioned path)
   unsigned long long errors;        // non-zero: a kernel hit a condition it cannot handle
   unsigned long long parse_fallback;  // fast parser saw a blank in a sequence line: re-parse generally
-  unsigned long long pad[2];
+  unsigned long long records;       // super-k-mer records written (partitioned nt path)
+  unsigned long long pad[1];
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
@@ -131,6 +132,9 @@ struct mk_ctx {
   double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
   int use_partition = 1;
   int use_fast_parse = 1;
+  int use_superkmer = 1;
+  int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
+  double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
@@ -163,6 +167,8 @@ int mk_launch_count_hash64(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_byref(mk_ctx* c, size_t seq_cap, bool exotic_only);
 // partitioned hash64 path: windows -> hash buckets -> per-bucket LDS tables -> survivors (count >= min_count)
 int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
+// super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip
+int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // tables
 int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
 int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);
@@ -170,6 +176,8 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
+int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
+                             const uint64_t* nsurv, size_t p1);
 int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows);
 // export helpers
 int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys, uint64_t* d_counts, size_t cap,

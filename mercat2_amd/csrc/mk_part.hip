@@ -209,15 +209,13 @@ __global__ __launch_bounds__(SCAT_THREADS) void mk_part_scatter_k(const u64* __r
 // whose distinct keys do not fit the LDS table is replaced by its two halves.
 #define CNT_U 4  // keys per thread in flight
 
-__device__ __forceinline__ void lds_insert_slow(u64* tkey, unsigned* tcnt, unsigned* s_distinct, unsigned* s_overflow,
-                                                u64 key, unsigned slot, u64 cur) {
-  for (int probe = 0; probe < CNT_SLOTS; ++probe) {
+#define CNT_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
+__device__ __forceinline__ void lds_insert_slow(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned slot,
+                                                u64 cur) {
+  for (int probe = 0; probe < CNT_MAX_PROBE; ++probe) {
     if (cur == MK_EMPTY) {
       cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
-      if (cur == MK_EMPTY) {
-        cur = key;
-        if (atomicAdd(s_distinct, 1u) >= CNT_LOADCAP) *(volatile unsigned*)s_overflow = 1;
-      }
+      if (cur == MK_EMPTY) cur = key;
     }
     if (cur == key) { atomicAdd(&tcnt[slot], 1u); return; }
     slot = (slot + 1) & (CNT_SLOTS - 1);
@@ -281,20 +279,19 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
       for (int u = 0; u < CNT_U; ++u) {
         if (kk[u] == MK_EMPTY) continue;
         if (cur[u] == kk[u]) atomicAdd(&tcnt[slot[u]], 1u);
-        else lds_insert_slow(tkey, tcnt, &s_distinct, &s_overflow, kk[u], slot[u], cur[u]);
+        else lds_insert_slow(tkey, tcnt, &s_overflow, kk[u], slot[u], cur[u]);
       }
       if (*(volatile unsigned*)&s_overflow) break;  // the table filled up: this attempt is void
     }
     __syncthreads();
     const bool over = s_overflow != 0;
-    const unsigned found = s_distinct;
     // ---- emit (when complete) and clear: count the keepers, reserve their output range with ONE
     //      global atomic per workgroup, then place them by an LDS cursor
     {
       constexpr int PER = CNT_SLOTS / CNT_THREADS;
       u64 ek[PER];
       unsigned ec[PER];
-      unsigned mine = 0;
+      unsigned mine = 0, occ = 0;
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const unsigned i = q * CNT_THREADS + threadIdx.x;
@@ -302,9 +299,12 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
         ec[q] = tcnt[i];
         tkey[i] = MK_EMPTY;
         tcnt[i] = 0;
+        occ += ek[q] != MK_EMPTY;
         if (over || ek[q] == MK_EMPTY || (u64)ec[q] < min_count) ek[q] = MK_EMPTY;
         mine += ek[q] != MK_EMPTY;
       }
+      for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+      if ((threadIdx.x & 63) == 0 && occ && !over) atomicAdd(&s_distinct, occ);
       if (mine) atomicAdd(&s_emit, mine);
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -313,6 +313,7 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
         s_emit = 0;
       }
       __syncthreads();
+      distinct_total += s_distinct;
       if (mine) {
         const u64 at = s_base + atomicAdd(&s_emit, mine);
         unsigned o = 0;
@@ -338,7 +339,6 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
       s += 1;
       idx <<= 1;
     } else {
-      distinct_total += found;
       while (s > s0 && (idx & 1u)) { idx >>= 1; --s; }
       if (s == s0) {
         ++idx;
@@ -349,6 +349,10 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
     }
   }
   if (threadIdx.x == 0) atomicAdd(&info->distinct, distinct_total);
+}
+
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2) {
+  hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, start, cursor, p1_log2);
 }
 
 // ------------------------------------------------------------------------------ launcher

@@ -1,0 +1,611 @@
+// mk_skmer.hip -- super-k-mer partitioned counting for nucleotide k-mers, 18 <= k <= 32.
+//
+// Same arithmetic as mk_part.hip (every window +1, keep count >= min_count;
+// lib/mercat2_kmers.py:56-60, 73-76) but the unit that travels through HBM is not the 8-byte
+// key of ONE window: it is a 16-byte record holding a run of up to 31 CONSECUTIVE windows that
+// share their minimizer (a "super-k-mer": nk + k - 1 bases, 2 bits each, plus nk in 6 bits).
+//
+//   minimizer of a window = the 11-mer inside it with the smallest hash (leftmost on ties): a
+//   function of the window's content only, so equal k-mers always meet in the same bucket;
+//   bucket = hash2(minimizer).  Consecutive windows usually keep their minimizer, so a run of
+//   ~8 windows costs one 16-byte store instead of eight scattered 8-byte stores, and the
+//   partition traffic drops from 8 B to ~2 B per window.
+//
+//   1 mk_sk_hist     per thread 32 windows: 11-mers, hashes, sliding minimum (doubling), runs;
+//                    records per bucket in an LDS histogram
+//   2 mk_part_scan   (mk_part.hip)
+//   3 mk_sk_scatter  same walk; rank of each record inside its (tile,bucket) run from an LDS
+//                    counter, one sweep of cursor atomics per tile, 16-byte record stores
+//   4 mk_sk_count    one workgroup per bucket: expand the records into k-mers and count them in
+//                    the LDS open-addressing table (same table, emit and sub-range splitting as
+//                    mk_part_count_k)
+#include "mk_common.h"
+#include "mk_device.h"
+#include <cstdlib>
+#include <cstdio>
+#include <vector>
+
+#define SK_M 11                 // minimizer length
+#define SK_MASK ((1u << (2 * SK_M)) - 1)
+#define SK_R 32                 // windows per thread
+#define SK_HIST_THREADS 256
+#define SK_SCAT_THREADS 1024
+#define SK_SCAT_SUBT 2
+#define SK_MAX_P1 8192
+#define SKC_SLOTS 8192
+#define SKC_LOADCAP (SKC_SLOTS / 2)
+#define SKC_TARGET (SKC_SLOTS * 4 / 10)
+#define SKC_THREADS 1024
+#define SKC_SUB_BITS 16
+
+static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {  // top 26 bits used for ordering
+  unsigned h = mm * 0x9E3779B1u;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  return h;
+}
+__device__ __forceinline__ unsigned sk_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
+
+// 11-mer starting at base q of the 64-base pair (w0,w1).
+__device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
+  u64 x;
+  if (q == 0) x = w0;
+  else if (q < 32) x = (w0 << (2 * q)) | (w1 >> (64 - 2 * q));
+  else x = w1 << (2 * (q - 32));  // q + SK_M <= 64: the 11-mer lies inside w1
+  return (unsigned)(x >> (64 - 2 * SK_M));
+}
+
+// Walks the thread's 32 windows and calls emit(jstart, nk, minimizer) for every record.
+// W = k - SK_M + 1 minimizer candidates per window (compile time: the sliding minimum is a
+// doubling network with static indices). nkmax bounds the run length.
+template <int W, class F>
+__device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, F&& emit) {
+  constexpr int NQ = SK_R + W - 1;  // candidate positions 0 .. NQ-1
+  unsigned ord[NQ];
+  {
+    unsigned mm = sk_mmer(w0, w1, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q) {
+        const int pos = q + SK_M - 1;  // new base index
+        const unsigned base = (unsigned)((pos < 32 ? (w0 >> (62 - 2 * pos)) : (w1 >> (62 - 2 * (pos - 32)))) & 3u);
+        mm = ((mm << 2) | base) & SK_MASK;
+      }
+      ord[q] = (sk_order_hash(mm) & ~63u) | (unsigned)q;
+    }
+  }
+  // sliding minimum over W consecutive candidates: doubling
+  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;
+#pragma unroll
+  for (int step = 1; step < P; step <<= 1) {
+#pragma unroll
+    for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
+  }
+  const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+  int open_start = -1, open_nk = 0;
+  unsigned open_pos = 0;
+#pragma unroll
+  for (int j = 0; j < SK_R; ++j) {
+    const bool valid = ((badw >> j) & kmask) == 0;
+    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;  // position of the window's minimizer
+    if (open_start >= 0 && (!valid || best != open_pos || open_nk >= nkmax)) {
+      emit(open_start, open_nk, sk_mmer(w0, w1, (int)open_pos));
+      open_start = -1;
+    }
+    if (valid) {
+      if (open_start < 0) { open_start = j; open_nk = 1; open_pos = best; }
+      else ++open_nk;
+    }
+  }
+  if (open_start >= 0) emit(open_start, open_nk, sk_mmer(w0, w1, (int)open_pos));
+}
+
+__device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart, int nk, int k) {
+  u64 hi = jstart ? ((w0 << (2 * jstart)) | (w1 >> (64 - 2 * jstart))) : w0;
+  u64 lo = jstart ? (w1 << (2 * jstart)) : w1;
+  const int L = nk + k - 1;  // bases, <= 61
+  if (L <= 32) { hi = (L == 32) ? hi : (hi & (~0ull << (64 - 2 * L))); lo = 0; }
+  else lo &= ~0ull << (128 - 2 * L);
+  lo |= (u64)nk;
+  return make_ulonglong2(hi, lo);
+}
+
+// ------------------------------------------------------------------------------ 1 hist
+template <int W>
+__global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                                MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
+                                                                u64* __restrict__ khist, int p1_log2, int k, int nkmax,
+                                                                size_t nthreads_total) {
+  __shared__ unsigned lh[SK_MAX_P1];  // records per bucket
+  __shared__ unsigned lk[SK_MAX_P1];  // k-mers per bucket (bounds the bucket's survivors)
+  const unsigned p1 = 1u << p1_log2;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) { lh[i] = 0; lk[i] = 0; }
+  __syncthreads();
+  const size_t seq_len = info->seq_len;
+  u64 mine = 0, recs = 0;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t p0 = t * SK_R;
+    if (p0 >= seq_len) break;
+    const u64 w0 = codes[t], w1 = codes[t + 1];
+    const u64 badw = bad_window(bad, p0);
+    sk_for_each_record<W>(w0, w1, badw, k, nkmax, [&](int, int nk, unsigned mm) {
+      const unsigned b = sk_bucket(mm, p1_log2);
+      atomicAdd(&lh[b], 1u);
+      atomicAdd(&lk[b], (unsigned)nk);
+      mine += (u64)nk;
+      ++recs;
+    });
+  }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < p1; b += blockDim.x) {
+    const unsigned v = lh[b];
+    if (v) {
+      atomicAdd(&hist[b], (u64)v);
+      atomicAdd(&khist[b], (u64)lk[b]);
+    }
+  }
+  wave_add(&info->windows, mine);
+  wave_add(&info->records, recs);
+}
+
+// --------------------------------------------------------------------------- 3 scatter
+template <int W>
+__global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                                   const MkChunkInfo* __restrict__ info,
+                                                                   u64* __restrict__ cursor, ulonglong2* __restrict__ part,
+                                                                   int p1_log2, int k, int nkmax, size_t ntiles) {
+  __shared__ unsigned lh[SK_MAX_P1];
+  __shared__ u64 gbase[SK_MAX_P1];
+  constexpr int NB = SK_MAX_P1 / SK_SCAT_THREADS;
+  const unsigned p1 = 1u << p1_log2;
+  const size_t seq_len = info->seq_len;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#pragma unroll 1
+    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
+      const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+      const size_t p0 = t * SK_R;
+      if (p0 >= seq_len) continue;
+      const u64 w0 = codes[t], w1 = codes[t + 1];
+      const u64 badw = bad_window(bad, p0);
+      sk_for_each_record<W>(w0, w1, badw, k, nkmax,
+                            [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+    }
+    __syncthreads();
+    {
+      unsigned v[NB];
+      u64 r[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        v[i] = b < p1 ? lh[b] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        if (b < p1) { gbase[b] = r[i]; lh[b] = 0; }
+      }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
+      const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+      const size_t p0 = t * SK_R;
+      if (p0 >= seq_len) continue;
+      const u64 w0 = codes[t], w1 = codes[t + 1];
+      const u64 badw = bad_window(bad, p0);
+      sk_for_each_record<W>(w0, w1, badw, k, nkmax, [&](int jstart, int nk, unsigned mm) {
+        const unsigned b = sk_bucket(mm, p1_log2);
+        part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk_make_record(w0, w1, jstart, nk, k);
+      });
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------ 4 count
+// Stage layout: entry g lives at skc_swz(g). Lane l writes entries ~8l+i (prefix sums of the record
+// lengths), i.e. a 64-byte lane stride that would put 32 lanes on 2 of the 16 eight-byte bank
+// pairs; rotating each 16-entry block by its block number spreads them over all 16 (2-way).
+__device__ __forceinline__ unsigned skc_swz(unsigned g) { return (g & ~15u) | ((g + (g >> 4)) & 15u); }
+
+// 32-bit hash of a packed key for the LDS table: bits 31..19 pick the slot, bits 15..0 the
+// sub-range (3 multiplies instead of the 8 of mk_mix64; only balance matters here).
+__device__ __forceinline__ unsigned skc_hash(u64 key) {
+  unsigned h = (unsigned)key * 0x9E3779B1u ^ (unsigned)(key >> 32) * 0x85EBCA77u;
+  h ^= h >> 15;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+
+#define SKC_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
+__device__ __forceinline__ void skc_insert(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
+  unsigned slot = h >> 19;  // SKC_SLOTS == 8192
+  u64 cur = tkey[slot];
+  for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
+      if (cur == MK_EMPTY) cur = key;
+    }
+    if (cur == key) { atomicAdd(&tcnt[slot], 1u); return; }
+    slot = (slot + 1) & (SKC_SLOTS - 1);
+    cur = tkey[slot];
+  }
+  atomicOr(s_overflow, 1u);  // (a plain volatile LDS store here trips a gfx950 backend assertion in ROCm 7.2)
+}
+
+#define SKC_STAGE 6144                        // keys staged per flush (48 KB)
+#define SKC_PER (SKC_STAGE / SKC_THREADS)     // staged keys per thread per flush
+
+#ifdef MK_STAMP
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
+#define STAMP_ADD(acc, t0) { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; }
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, t0)
+#endif
+
+// Persistent: gridDim.x workgroups (one per CU) walk the buckets b = blockIdx.x, +gridDim.x, ...
+// The next bucket's bounds and its first two record batches are loaded while the current
+// bucket is being emitted, so no global-memory latency sits on the critical path.
+__global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
+                                                             const u64* __restrict__ kstart, u64* __restrict__ nsurv,
+                                                             MkChunkInfo* __restrict__ info, u64 min_count,
+                                                             u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
+                                                             int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg) {
+  __shared__ u64 tkey[SKC_SLOTS];
+  __shared__ unsigned tcnt[SKC_SLOTS];
+  __shared__ u64 stage[SKC_STAGE];
+  __shared__ unsigned wsum[SKC_THREADS / 64];
+  __shared__ unsigned s_distinct, s_overflow, s_emit;
+  for (unsigned i = threadIdx.x; i < SKC_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
+  if (threadIdx.x == 0) { s_distinct = 0; s_overflow = 0; s_emit = 0; }
+  __syncthreads();
+  const int kshift = 64 - 2 * k;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
+  u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, npass = 0;
+  STAMP(t0);
+
+  // prefetched state of the bucket about to be processed
+  unsigned bn = blockIdx.x;
+  u64 lo_n = 0, hi_n = 0, ks_n = 0;
+  ulonglong2 pre[2] = {make_ulonglong2(0, 0), make_ulonglong2(0, 0)};
+  if (bn < p1) {
+    lo_n = start[bn];
+    hi_n = start[bn + 1];
+    ks_n = kstart[bn];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+      if (j < hi_n - lo_n) pre[h] = part[lo_n + j];
+    }
+  }
+  for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
+    const u64 lo = lo_n, n = hi_n - lo_n;  // records of this bucket
+    u64* __restrict__ my_keys = out_keys + ks_n;
+    u64* __restrict__ my_cnts = out_cnts + ks_n;
+    ulonglong2 first[2] = {pre[0], pre[1]};
+    // bounds of the next bucket: in flight while this one is counted
+    bn = b + gridDim.x;
+    if (bn < p1) {
+      lo_n = start[bn];
+      hi_n = start[bn + 1];
+      ks_n = kstart[bn];
+    }
+    unsigned emitted = 0;
+    if (n >> 27) {  // 2^27 records x 31 k-mers would overflow the 32-bit LDS counters
+      ++nerr;
+    } else if (n) {
+      int s0 = 0;
+      {
+        const double expect = (double)n * nk_hint / (dup_hint > 1.0 ? dup_hint : 1.0);
+        while (s0 < SKC_SUB_BITS && expect / (double)(1u << s0) > (double)SKC_TARGET) ++s0;
+        if ((double)n * 31.0 <= (double)SKC_LOADCAP) s0 = 0;
+      }
+      int s = s0;
+      unsigned idx = 0;
+      u64 side_pass = 0;
+      bool side_done = false;
+      bool first_pass = true;
+      const ulonglong2* __restrict__ src = part + lo;
+      for (;;) {
+        const unsigned sel_shift = SKC_SUB_BITS - s;
+        side_pass = 0;  // the all-ones key (32 x 'T') is counted aside, once per bucket
+        bool over = false;
+        for (u64 rb2 = 0; rb2 < n && !over; rb2 += 2 * SKC_THREADS) {
+          ulonglong2 recs2[2];
+          if (first_pass && rb2 == 0) {
+            recs2[0] = first[0];
+            recs2[1] = first[1];
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const u64 j = rb2 + (u64)h * SKC_THREADS + threadIdx.x;
+              recs2[h] = j < n ? src[j] : make_ulonglong2(0, 0);
+            }
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (rb2 + (u64)h * SKC_THREADS >= n || over) break;
+            const ulonglong2 rec = recs2[h];
+            STAMP_ADD(tF, t0);
+            // ---- exclusive scan of the record lengths over the workgroup
+            const unsigned nk = (unsigned)(rec.y & 63);
+            unsigned inc = nk;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const unsigned up = __shfl_up(inc, d);
+              if (lane >= d) inc += up;
+            }
+            if (lane == 63) wsum[wv] = inc;
+            __syncthreads();
+            unsigned pfx = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < SKC_THREADS / 64; ++w) {
+              const unsigned v = wsum[w];
+              if (w < wv) pfx += v;
+              total += v;
+            }
+            const unsigned off = pfx + inc - nk;
+            STAMP_ADD(tA, t0);
+            for (unsigned f = 0; f < total; f += SKC_STAGE) {
+              // ---- expand: this thread's k-mers with staged index in [f, f + SKC_STAGE)
+              {
+                const unsigned g_lo = off > f ? off : f;
+                const unsigned g_hi = (off + nk < f + SKC_STAGE) ? off + nk : f + SKC_STAGE;
+                const unsigned i_lo = g_lo < g_hi ? g_lo - off : 0u;
+                const unsigned i_hi = g_lo < g_hi ? g_hi - off : 0u;
+                if (i_lo < i_hi) {
+                  u64 x = rec.x, y = rec.y;
+                  if (i_lo) {
+                    const unsigned sh = 2 * i_lo;  // 2..60
+                    x = (x << sh) | (y >> (64 - sh));
+                    y <<= sh;
+                  }
+                  unsigned g = off + i_lo - f;
+                  for (unsigned i = i_lo; i < i_hi; ++i, ++g) {
+                    stage[skc_swz(g)] = x >> kshift;
+                    x = (x << 2) | (y >> 62);
+                    y <<= 2;
+                  }
+                }
+              }
+              __syncthreads();
+              STAMP_ADD(tB, t0);
+              // ---- insert: SKC_PER staged keys per thread, first probes issued together
+              {
+                const unsigned cntk = total - f < SKC_STAGE ? total - f : SKC_STAGE;
+                u64 kk[SKC_PER], cur[SKC_PER];
+                unsigned hh[SKC_PER];
+#pragma unroll
+                for (int u = 0; u < SKC_PER; ++u) {
+                  const unsigned g = threadIdx.x + u * SKC_THREADS;
+                  kk[u] = g < cntk ? stage[skc_swz(g)] : MK_EMPTY;
+                  if (g < cntk && kk[u] == MK_EMPTY) side_pass += side_done ? 0 : 1;
+                }
+#pragma unroll
+                for (int u = 0; u < SKC_PER; ++u) {
+                  hh[u] = skc_hash(kk[u]);
+                  if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) kk[u] = MK_EMPTY;
+                }
+#pragma unroll
+                for (int u = 0; u < SKC_PER; ++u) cur[u] = tkey[hh[u] >> 19];
+#pragma unroll
+                for (int u = 0; u < SKC_PER; ++u) {
+                  if (kk[u] == MK_EMPTY) continue;
+                  const unsigned slot = hh[u] >> 19;
+                  if (cur[u] == kk[u]) atomicAdd(&tcnt[slot], 1u);
+                  else skc_insert(tkey, tcnt, &s_overflow, kk[u], hh[u]);
+                }
+              }
+              __syncthreads();
+              STAMP_ADD(tC, t0);
+              if (s_overflow) { over = true; break; }
+            }
+          }
+        }
+        first_pass = false;
+        __syncthreads();
+        STAMP_ADD(tF, t0);
+        ++npass;
+        over = s_overflow != 0;
+        // will this be the bucket's last pass? then start loading the next bucket's records now
+        bool last = false;
+        if (!over) {
+          int s2 = s;
+          unsigned i2 = idx;
+          while (s2 > s0 && (i2 & 1u)) { i2 >>= 1; --s2; }
+          last = (s2 == s0) && (i2 + 1 >= (1u << s0));
+        }
+        if (last && bn < p1) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+            pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
+          }
+        }
+        // ---- emit (when complete) into the bucket's own region, and clear
+        {
+          constexpr int PER = SKC_SLOTS / SKC_THREADS;
+          u64 ek[PER];
+          unsigned ec[PER];
+          unsigned mine = 0, occ = 0;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const unsigned i = q * SKC_THREADS + threadIdx.x;
+            ek[q] = tkey[i];
+            ec[q] = tcnt[i];
+            tkey[i] = MK_EMPTY;
+            tcnt[i] = 0;
+            occ += ek[q] != MK_EMPTY;
+            if (over || ek[q] == MK_EMPTY || (u64)ec[q] < min_count) ek[q] = MK_EMPTY;
+            mine += ek[q] != MK_EMPTY;
+          }
+          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          if (lane == 0 && occ && !over) atomicAdd(&s_distinct, occ);
+          if (mine) {
+            const unsigned at = emitted + atomicAdd(&s_emit, mine);  // LDS cursor inside the region
+            unsigned o = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              if (ek[q] != MK_EMPTY) {
+                my_keys[at + o] = ek[q];
+                my_cnts[at + o] = ec[q];
+                ++o;
+              }
+            }
+          }
+          __syncthreads();
+          emitted += s_emit;
+          distinct_total += s_distinct;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_distinct = 0; s_overflow = 0; s_emit = 0; }
+        __syncthreads();
+        STAMP_ADD(tD, t0);
+        if (over) {
+          if (s >= SKC_SUB_BITS) { ++nerr; break; }
+          s += 1;
+          idx <<= 1;
+        } else {
+          side += side_pass;
+          side_done = true;
+          while (s > s0 && (idx & 1u)) { idx >>= 1; --s; }
+          if (s == s0) {
+            ++idx;
+            if (idx >= (1u << s0)) break;
+          } else {
+            ++idx;
+          }
+        }
+      }
+    }
+    if (n == 0 || (n >> 27)) {
+      // nothing was prefetched for the next bucket by a "last pass": do it here
+      if (bn < p1) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+          pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
+        }
+      }
+    }
+    if (threadIdx.x == 0) nsurv[b] = emitted;
+    survivors_total += emitted;
+    STAMP_ADD(tE, t0);
+  }
+  if (threadIdx.x == 0) {
+    if (distinct_total) atomicAdd(&info->distinct, distinct_total);
+    if (survivors_total) atomicAdd(&info->survivors, survivors_total);
+    if (nerr) atomicAdd(&info->errors, nerr);
+#ifdef MK_STAMP
+    if (dbg) { u64* d = dbg + (size_t)blockIdx.x * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = tF; d[6] = npass; }
+#endif
+  }
+  wave_add(&info->side, side);
+}
+
+// ------------------------------------------------------------------------------ launcher
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2);  // mk_part.hip
+
+template <int W>
+static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, u64* hist, u64* start, u64* cursor, u64* khist) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const size_t threads = div_up(seq_len, SK_R), tiles = div_up(threads, SK_HIST_THREADS);
+  const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
+  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(SK_HIST_THREADS), 0, c->stream,
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads);
+  mk_launch_part_scan(c, hist, start, cursor, p1_log2);
+  hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
+                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (ulonglong2*)c->part.p, p1_log2,
+                     c->k, nkmax, stiles);
+}
+
+#ifdef MK_STAMP
+u64* mk_dbg_ptr = nullptr;
+#endif
+
+int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const int k = c->k;
+  // ~1.2K records (~10K windows) per bucket, between 256 and SK_MAX_P1 buckets
+  int p1_log2 = 8;
+  while (p1_log2 < 13 && (seq_len >> p1_log2) > 8192) ++p1_log2;
+  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= 13) p1_log2 = v; }
+  c->p1_log2 = p1_log2;
+  const size_t p1 = (size_t)1 << p1_log2;
+  int nkmax = 62 - k;
+  if (nkmax > 31) nkmax = 31;
+  int rc;
+  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
+  // worst case one record per window
+  if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(ulonglong2))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_keys, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_cnts, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  u64* hist = (u64*)c->part_meta.p;
+  u64* start = hist + p1;
+  u64* cursor = start + p1 + 1;
+  u64* khist = cursor + p1;
+  u64* kstart = khist + p1;
+  u64* kcursor = kstart + p1 + 1;
+  u64* nsurv = kcursor + p1;
+  MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
+  mk_prof_begin(c, MK_K_COUNT);
+  switch (k - SK_M + 1) {
+#define SK_CASE(W) case W: launch_w<W>(c, seq_len, p1_log2, nkmax, hist, start, cursor, khist); break;
+    SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
+    SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
+#undef SK_CASE
+    default:
+      c->err = "mk_launch_count_superkmer: k out of range";
+      return MK_ERR_ARG;
+  }
+  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2);
+  {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
+    u64* dbgbuf = nullptr;
+#ifdef MK_STAMP
+    if (!mk_dbg_ptr) (void)hipMalloc((void**)&mk_dbg_ptr, 8 * 8 * 1024);
+    dbgbuf = mk_dbg_ptr;
+#endif
+    hipLaunchKernelGGL(mk_sk_count_k, dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p,
+                       (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                       (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf);
+  }
+  mk_prof_end(c);
+#ifdef MK_STAMP
+  {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    std::vector<u64> h(8 * ncu);
+    (void)hipStreamSynchronize(c->stream);
+    u64* d = nullptr;
+    {
+      static u64* s_dbg2 = nullptr; (void)s_dbg2;
+    }
+    d = mk_dbg_ptr;
+    if (d) { (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+      double a[7] = {0,0,0,0,0,0,0}; for (int w = 0; w < ncu; ++w) for (int q = 0; q < 7; ++q) a[q] += (double)h[w * 8 + q] / ncu;
+      fprintf(stderr, "[stamp] per-WG cycles: scan=%.0f expand=%.0f insert=%.0f emit=%.0f bucket_tail=%.0f other=%.0f passes=%.1f\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6]); }
+  }
+#endif
+  MK_HIP(hipGetLastError());
+  c->surv_regions = 1;
+  return MK_OK;
+}

@@ -96,6 +96,29 @@ __global__ void mk_import_pairs_k(const u64* __restrict__ keys, const u64* __res
   block_add(new_rows, fresh);
 }
 
+// Survivors laid out per bucket: bucket b holds nsurv[b] pairs from kstart[b] on. One wave per bucket.
+__global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, const u64* __restrict__ kstart,
+                                    const u64* __restrict__ nsurv, size_t p1, MkSlot* __restrict__ run, u64 run_mask,
+                                    u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  const int lane = threadIdx.x & 63;
+  for (size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < p1; b += (size_t)gridDim.x * (blockDim.x >> 6)) {
+    const u64 base = kstart[b], n = nsurv[b];
+    for (u64 i = lane; i < n; i += 64) fresh += upsert64(run, run_mask, keys[base + i], cnts[base + i]) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+
+int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
+                             const uint64_t* nsurv, size_t p1) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                     (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
+                     (u64)(c->run_slots - 1), &info->new_rows);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 __global__ void mk_import_bins_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
                                  u64* __restrict__ bins, size_t nbins) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)

@@ -55,7 +55,8 @@ def test_golden_matrix(fname, cases):
         with native.Counter(case["k"], alphabet_for(fname)) as ctx:
             ctx.count_chunk(data, case["c"])
             got = digest_of(ctx, case["basename"])
-        assert got == {k: case[k] for k in ("rows", "sum", "sha256")}, (fname, case["k"], case["c"], ctx.stats()["mode_name"])
+            mode = ctx.stats()["mode_name"]
+        assert got == {k: case[k] for k in ("rows", "sum", "sha256")}, (fname, case["k"], case["c"], mode)
 
 
 @pytest.mark.parametrize("alphabet", [native.ALPHABET_RAW, native.ALPHABET_NT2, native.ALPHABET_AA5],
