@@ -13,9 +13,12 @@ N > 1 (weak scaling): every rank counts its own 10M reads (same genome, disjoint
   indices), then the ranks merge their tables.
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the hash-table count kernel; achieved = algorithmic bytes per
-               launch (windows*16 B + symbols*0.25 B) / mean launch time measured
-               with HIP events on the engine's stream; peak = 8 TB/s HBM3E.
+  roofline     dominant kernel = the LDS count kernel (mk_sk_count_k); achieved = algorithmic
+               bytes per launch (windows * 16 B: one 8-byte key compare + one 8-byte count
+               read-modify-write per window, SURVEY.md 8d / DESIGN.md) / mean launch time measured
+               with HIP events on the engine's stream; peak = 8 TB/s HBM3E.  `stage_*` repeat the
+               calculation for the whole counting stage (partition + count kernels, + the 0.25 B
+               per symbol packed read).
   cpu_baseline the CPU oracle (Python restatement of the reference, oracle/cpu_ref.py) timed on
                this box's host cores on a bounded sample at the same coverage.
 """
@@ -154,8 +157,16 @@ def main():
         value = bases_rank * world * args.steps / dt
         launches = max(1, st["n_count"])
         ms_launch = st["ms_count"] / launches
-        alg_bytes = (st["windows"] - st["exotic_windows"]) * 16 + st["symbols"] * 0.25  # over all timed launches
+        packed_windows = st["windows"] - st["exotic_windows"]
+        alg_bytes = packed_windows * 16  # over all timed launches of the count kernel
         achieved = alg_bytes / launches / (ms_launch * 1e-3) / 1e9 if ms_launch > 0 else 0.0
+        stage_ms = (st["ms_count"] + st["ms_part"]) / launches
+        stage_bytes = packed_windows * 16 + st["symbols"] * 0.25
+        stage_achieved = stage_bytes / launches / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
+        kernel_name = {"hash64": "mk_sk_count_k" if 18 <= k <= 32 else "mk_part_count_k", "dense": "mk_count_dense_k",
+                       "byref": "mk_count_byref_k"}.get(st["mode_name"], "?")
+        if os.environ.get("MK_NO_PARTITION"):
+            kernel_name = "mk_count_hash64_k"
         line = {
             "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -167,11 +178,13 @@ def main():
                        "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
             "distinct_kmers_per_s": total_rows * args.steps / dt,
             "rows": total_rows,
-            "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "count", "exotic", "filter", "export")},
-            "roofline": {"bound": "hbm", "kernel": "mk_count_hash64_k", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "part", "count", "exotic", "filter", "export")},
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "launches": launches, "ms_per_launch": ms_launch,
-                         "algorithmic_bytes_per_launch": alg_bytes / launches},
+                         "algorithmic_bytes_per_launch": alg_bytes / launches,
+                         "stage_ms_per_launch": stage_ms, "stage_achieved": stage_achieved,
+                         "stage_frac": stage_achieved / HBM_PEAK_GBS},
             "input_gen_s": gen_s,
         }
         if not args.no_cpu and world == 1:

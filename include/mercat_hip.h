@@ -58,6 +58,12 @@ typedef struct mk_stats_t {
   /* HIP-event time per kernel family, milliseconds, and launches (only when profiled) */
   double ms_parse, ms_pack, ms_count, ms_exotic, ms_filter, ms_export;
   uint64_t n_parse, n_pack, n_count, n_exotic, n_filter, n_export;
+  /* partition stage (bucket histogram + scan + scatter) that feeds the LDS count kernel;
+   * ms_count / n_count are the count kernel alone */
+  double ms_part;
+  uint64_t n_part;
+  uint64_t records;  /* super-k-mer records written (0 on other paths) */
+  uint64_t distinct; /* distinct packed keys seen per chunk, summed over chunks */
 } mk_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -85,8 +85,8 @@ void mk_prof_end(mk_ctx* c) {
 static void prof_collect(mk_ctx* c) {
   if (c->events.empty()) return;
   (void)hipStreamSynchronize(c->stream);
-  double* ms[MK_K_NUM] = {&c->st.ms_parse, &c->st.ms_pack, &c->st.ms_count, &c->st.ms_exotic, &c->st.ms_filter, &c->st.ms_export};
-  uint64_t* nn[MK_K_NUM] = {&c->st.n_parse, &c->st.n_pack, &c->st.n_count, &c->st.n_exotic, &c->st.n_filter, &c->st.n_export};
+  double* ms[MK_K_NUM] = {&c->st.ms_parse, &c->st.ms_pack, &c->st.ms_count, &c->st.ms_exotic, &c->st.ms_filter, &c->st.ms_export, &c->st.ms_part};
+  uint64_t* nn[MK_K_NUM] = {&c->st.n_parse, &c->st.n_pack, &c->st.n_count, &c->st.n_exotic, &c->st.n_filter, &c->st.n_export, &c->st.n_part};
   for (auto& p : c->events) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) {
@@ -372,6 +372,8 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   c->st.windows += c->h_info->windows + c->h_info->exotic;
   c->st.exotic_windows += c->h_info->exotic;
   c->st.chunks += 1;
+  c->st.records += c->h_info->records;
+  c->st.distinct += c->h_info->distinct;
   c->st.survivors += c->h_info->survivors + c->h_info->survivors_ref +
                      ((c->h_info->side && c->h_info->side >= min_count) ? 1 : 0);
   return MK_OK;

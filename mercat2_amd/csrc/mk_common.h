@@ -58,7 +58,7 @@ struct MkChunkInfo {
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
-enum MkKernelId { MK_K_PARSE = 0, MK_K_PACK, MK_K_COUNT, MK_K_EXOTIC, MK_K_FILTER, MK_K_EXPORT, MK_K_NUM };
+enum MkKernelId { MK_K_PARSE = 0, MK_K_PACK, MK_K_COUNT, MK_K_EXOTIC, MK_K_FILTER, MK_K_EXPORT, MK_K_PART, MK_K_NUM };
 
 // 64-bit finaliser (splitmix64 / murmur3 style): bijective, mixes every input bit into every
 // output bit -- used to pick the home slot of a packed key.

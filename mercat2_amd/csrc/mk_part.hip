@@ -375,7 +375,7 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   u64* start = hist + p1;
   u64* cursor = start + p1 + 1;
   MK_HIP(hipMemsetAsync(hist, 0, p1 * sizeof(u64), c->stream));
-  mk_prof_begin(c, MK_K_COUNT);
+  mk_prof_begin(c, MK_K_PART);
   if (c->alphabet == MK_ALPHABET_NT2) {
     const size_t threads = div_up(seq_len, 32), tiles = div_up(threads, PART_THREADS);
     const size_t stiles = div_up(threads, (size_t)SCAT_THREADS * SCAT_SUBT);
@@ -397,6 +397,8 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (u64*)c->part.p, p1_log2,
                        c->k, stiles, dbg);
   }
+  mk_prof_end(c);
+  mk_prof_begin(c, MK_K_COUNT);
   hipLaunchKernelGGL(mk_part_count_k, dim3((unsigned)p1), dim3(CNT_THREADS), 0, c->stream, (const u64*)c->part.p,
                      (const u64*)start, info, (u64)min_count, (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, p1_log2,
                      c->dup_hint, dbg);

@@ -564,7 +564,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   u64* kcursor = kstart + p1 + 1;
   u64* nsurv = kcursor + p1;
   MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
-  mk_prof_begin(c, MK_K_COUNT);
+  mk_prof_begin(c, MK_K_PART);
   switch (k - SK_M + 1) {
 #define SK_CASE(W) case W: launch_w<W>(c, seq_len, p1_log2, nkmax, hist, start, cursor, khist); break;
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
@@ -575,6 +575,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
       return MK_ERR_ARG;
   }
   mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2);
+  mk_prof_end(c);
+  mk_prof_begin(c, MK_K_COUNT);
   {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
