@@ -198,3 +198,67 @@ def test_full_size_properties_config2():
         ctx.count_chunk(memoryview(data)[cut[1]:cut[2]], 1)
         kmers2, counts2 = ctx.export()
     assert np.array_equal(kmers, kmers2) and np.array_equal(counts, counts2)
+
+
+def _merge_sorted_tables(tables, k):
+    """Sum (kmers, counts) tables per key with numpy; result sorted by key bytes."""
+    keys = np.concatenate([t[0].reshape(-1, k).view("S%d" % k).reshape(-1) for t in tables])
+    cnts = np.concatenate([t[1] for t in tables])
+    uniq, inv = np.unique(keys, return_inverse=True)
+    out = np.zeros(uniq.size, dtype=np.uint64)
+    np.add.at(out, inv, cnts)
+    return uniq, out
+
+
+def test_config2_full_size_bit_exact_vs_c_oracle():
+    """BASELINE config 2 (S1): 1M x 150 bp, genome 1 Mbp (seeds 1/2), k=21, -c 10 -- the whole
+    table, bit for bit, against the C oracle: unchunked (-s 0) and with the reference's chunking
+    at -s 100 (2 chunks, each filtered on its own before the merge)."""
+    from oracle import c_oracle
+    k, c = 21, 10
+    data = native.synth_reads(1_000_000, 1, 1_000_000, 150, 2).tobytes()
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, c)
+        kmers, counts = ctx.export()
+    okm, ocn = c_oracle.count(data, k, c)
+    assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn)
+    offs = chunk_offsets(data, 100 * 1024 * 1024)
+    assert len(offs) == 3
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        for a, b in zip(offs[:-1], offs[1:]):
+            ctx.count_chunk(memoryview(data)[a:b], c)
+        kmers2, counts2 = ctx.export()
+    want_k, want_c = _merge_sorted_tables([c_oracle.count(data[a:b], k, c) for a, b in zip(offs[:-1], offs[1:])], k)
+    assert np.array_equal(kmers2.view("S%d" % k).reshape(-1), want_k) and np.array_equal(counts2, want_c)
+    assert counts2.size < counts.size  # the per-chunk filter loses k-mers (README "least significant k-mers")
+
+
+@pytest.mark.parametrize("k,sub_ppm", [(31, 0), (32, 10000), (18, 0), (25, 0)])
+def test_superkmer_path_vs_c_oracle(k, sub_ppm):
+    """300k reads (45 Mbases) through the super-k-mer kernels at several k, incl. k=32 (all-ones key)
+    and 1 % substitutions (more distinct keys per bucket)."""
+    from oracle import c_oracle
+    data = native.synth_reads(300_000, 21, 300_000, 150, 22, sub_ppm).tobytes() + b">polyT\n" + b"T" * 5000 + b"\n"
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, 2)
+        kmers, counts = ctx.export()
+    okm, ocn = c_oracle.count(data, k, 2)
+    assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn)
+
+
+def test_bucket_overflow_splits_sub_ranges():
+    """All-distinct keys (uniform random reads, nothing repeats) overflow the LDS tables' target
+    load and force the sub-range splitting of the count kernel; the result must not change."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(7)
+    seq = rng.integers(0, 4, size=(40_000, 150), dtype=np.uint8)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    body = lut[seq]
+    lines = [b">u%d\n" % i + body[i].tobytes() + b"\n" for i in range(body.shape[0])]
+    data = b"".join(lines)
+    for k in (31, 21, 12):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, 1)
+            kmers, counts = ctx.export()
+        okm, ocn = c_oracle.count(data, k, 1)
+        assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
