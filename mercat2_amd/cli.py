@@ -1,0 +1,94 @@
+"""Command line of the counting path, flag-compatible with bin/mercat2.py (lines 41-50, 68-79,
+207-215, 253-283, 312-346, 411-448 of the reference): -i/-f/-k/-n/-c/-s/-o/-replace.
+
+Only the count phase is implemented here: inputs are FASTA (nucleotide or
+protein; plain or .gz). FASTQ conversion, N-cleaning, ORF calling, reports and plots belong to
+the reference's other layers and are not part of this engine.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import sys
+import timeit
+from pathlib import Path
+
+from . import __version__
+from .harness import run_sample
+
+FILE_EXT_NUCLEOTIDE = [".fasta", ".fa", ".fna", ".ffn", ".fasta.gz", ".fa.gz", ".fna.gz", ".ffn.gz"]
+FILE_EXT_PROTEIN = [".faa", ".faa.gz"]
+
+
+def parseargs(argv=None):
+    p = argparse.ArgumentParser(description="MerCat2 k-mer counting on MI355X (count phase only)")
+    p.add_argument("-i", required=False, default=list(), help="path to input file", nargs="+")
+    p.add_argument("-f", type=str, required=False, help="path to folder containing input files")
+    p.add_argument("-k", type=int, required=True, help="kmer length")
+    p.add_argument("-n", type=int, default=os.cpu_count() or 1, help="no of cores [auto detect] (accepted, unused)")
+    p.add_argument("-c", type=int, default=10, help="minimum kmer count [10]")
+    p.add_argument("-s", type=int, default=100, required=False, help="Split into x MB files. [100]")
+    p.add_argument("-o", type=str, default="mercat_results", required=False, help="Output folder")
+    p.add_argument("-replace", action="store_true", help="Replace existing output directory [False]")
+    p.add_argument("-gpu", type=int, default=0, help="HIP device index [0]")
+    p.add_argument("--version", "-v", action="version", version=f"mercat2_amd {__version__}")
+    args = p.parse_args(argv)
+    if not args.i and not args.f:
+        p.error("Please provide either an input file (-i) or an input folder (-f)")
+    for filename in args.i:
+        if not os.path.isfile(filename):
+            p.error(f"file '{filename}' is not valid.\n")
+    if args.f and not os.path.isdir(args.f):
+        p.error(f"folder {args.f} is not valid.\n")
+    return args, p
+
+
+def classify(path: Path):
+    """(type, basename) by the reference's extension tables (bin/mercat2.py:26-28, 264-283)."""
+    suffixes = path.suffixes
+    ext = ""
+    for i in reversed(range(len(suffixes))):
+        cand = "".join(suffixes[i:])
+        if cand in FILE_EXT_NUCLEOTIDE + FILE_EXT_PROTEIN:
+            ext = cand
+    if not ext:
+        return None, None
+    base = path.name[: -len(ext)]
+    return ("protein" if ext in FILE_EXT_PROTEIN else "nucleotide"), base
+
+
+def main(argv=None) -> int:
+    args, parser = parseargs(argv)
+    out = Path(args.o)
+    if out.exists():
+        if args.replace:
+            shutil.rmtree(out)
+        else:
+            parser.error(f"Output folder exists, please specify another folder or use the flag '-replace' to override the files. '{out}'")
+    out.mkdir(0o777, True, True)
+    print(f"\nStarting mercat2_amd v{__version__} with k-mer {args.k} on GPU {args.gpu}\n")
+    files = [Path(f) for f in args.i]
+    if args.f:
+        folder = Path(os.path.abspath(os.path.expanduser(args.f)))
+        files += [folder / name for name in sorted(os.listdir(folder)) if (folder / name).is_file()]
+    samples = {"nucleotide": {}, "protein": {}}
+    for f in files:
+        kind, base = classify(f.expanduser().absolute())
+        if kind:
+            samples[kind][base] = f
+    for kind in ("nucleotide", "protein"):
+        if not samples[kind]:
+            continue
+        print("Processing Nucleotides" if kind == "nucleotide" else "Processing protein")
+        tsv_dir = out / f"tsv_{kind}"
+        tsv_dir.mkdir(parents=True, exist_ok=True)
+        start = timeit.default_timer()
+        for base, f in samples[kind].items():
+            run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu)
+        print(f"Time to count {args.k}-mers: {round(timeit.default_timer() - start, 2)} seconds")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

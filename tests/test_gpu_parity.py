@@ -262,3 +262,22 @@ def test_bucket_overflow_splits_sub_ranges():
             kmers, counts = ctx.export()
         okm, ocn = c_oracle.count(data, k, 1)
         assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
+
+
+def test_cli_writes_reference_tsv(tmp_path, capsys):
+    """python -m mercat2_amd.cli with the reference's flags: same file name and bytes as the
+    reference's committed table for RW1_pro (k=5, -c 10)."""
+    from mercat2_amd import cli
+    out = tmp_path / "res"
+    src = tmp_path / "RW1_pro.faa"
+    src.write_bytes(read_input("RW1_pro.faa.gz"))
+    assert cli.main(["-i", str(src), "-k", "5", "-c", "10", "-o", str(out)]) == 0
+    got = (out / "tsv_protein" / "RW1_pro_counts.tsv").read_text()
+    assert got == (GOLDEN / "tsv" / "ref_RW1_pro_k5_c10.tsv").read_text()
+    text = capsys.readouterr().out
+    assert "Significant k-mers:" in text and "Time to count 5-mers:" in text
+    # nothing survives -> no file, sample dropped (bin/mercat2.py:135-137)
+    out2 = tmp_path / "res2"
+    assert cli.main(["-i", str(src), "-k", "5", "-c", "100000", "-o", str(out2)]) == 0
+    assert not (out2 / "tsv_protein" / "RW1_pro_counts.tsv").exists()
+    assert "No significant k-mers found" in capsys.readouterr().out
