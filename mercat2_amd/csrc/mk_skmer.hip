@@ -28,9 +28,10 @@
 #define SK_M 11                 // minimizer length
 #define SK_MASK ((1u << (2 * SK_M)) - 1)
 #define SK_R 32                 // windows per thread
+#define SK_NKMAX 8              // windows per record (<= 62 - k)
 #define SK_HIST_THREADS 256
 #define SK_SCAT_THREADS 1024
-#define SK_SCAT_SUBT 2
+#define SK_SCAT_SUBT 4
 #define SK_MAX_P1 8192
 #define SKC_SLOTS 8192
 #define SKC_LOADCAP (SKC_SLOTS / 2)
@@ -84,23 +85,44 @@ __device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int
 #pragma unroll
     for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
   }
+  // Pass 1 (static, branch-free): which windows are valid, where each window's minimizer sits,
+  // and where a new run starts (first valid window, minimizer moved, or previous window invalid).
   const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
-  int open_start = -1, open_nk = 0;
-  unsigned open_pos = 0;
+  unsigned valid = 0, starts = 0;
+  u64 pos_a = 0, pos_b = 0, pos_c = 0, pos_d = 0;  // 6-bit minimizer positions of windows 0-9, 10-19, 20-29, 30-31
+  unsigned prev_pos = 64;                   // impossible position: window 0 always starts a run
 #pragma unroll
   for (int j = 0; j < SK_R; ++j) {
-    const bool valid = ((badw >> j) & kmask) == 0;
-    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;  // position of the window's minimizer
-    if (open_start >= 0 && (!valid || best != open_pos || open_nk >= nkmax)) {
-      emit(open_start, open_nk, sk_mmer(w0, w1, (int)open_pos));
-      open_start = -1;
-    }
-    if (valid) {
-      if (open_start < 0) { open_start = j; open_nk = 1; open_pos = best; }
-      else ++open_nk;
+    const bool ok = ((badw >> j) & kmask) == 0;
+    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
+    valid |= ok ? (1u << j) : 0u;
+    starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
+    prev_pos = ok ? best : 64u;
+    if (j < 10) pos_a |= (u64)best << (6 * j);
+    else if (j < 20) pos_b |= (u64)best << (6 * (j - 10));
+    else if (j < 30) pos_c |= (u64)best << (6 * (j - 20));
+    else pos_d |= (u64)best << (6 * (j - 30));
+  }
+  // Pass 2 (dynamic, one iteration per run): a run ends at the next start, the next invalid
+  // window, the end of the thread's span, or after nkmax windows.
+  unsigned todo = starts;
+  while (todo) {
+    const int j = __ffs(todo) - 1;
+    todo &= todo - 1;
+    // windows j.. stay in the run while valid and not a start
+    const unsigned stop = (starts | ~valid) & ~((2u << j) - 1);  // bits above j that end the run
+    int nk = (stop ? (__ffs(stop) - 1) : SK_R) - j;
+    const u64 pw = j < 10 ? pos_a : (j < 20 ? pos_b : (j < 30 ? pos_c : pos_d));
+    const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
+    const unsigned mm = sk_mmer(w0, w1, (int)best);
+    int at = j;
+    while (nk > 0) {  // runs longer than a record holds are cut (same minimizer, same bucket)
+      const int take = nk < nkmax ? nk : nkmax;
+      emit(at, take, mm);
+      at += take;
+      nk -= take;
     }
   }
-  if (open_start >= 0) emit(open_start, open_nk, sk_mmer(w0, w1, (int)open_pos));
 }
 
 __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart, int nk, int k) {
@@ -231,8 +253,9 @@ __device__ __forceinline__ unsigned skc_hash(u64 key) {
 }
 
 #define SKC_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
-__device__ __forceinline__ void skc_insert(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
-  unsigned slot = h >> 19;  // SKC_SLOTS == 8192
+// Linear probing from the slot after the home slot (the caller has seen the home slot taken by another key).
+__device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
+  unsigned slot = ((h >> 19) + 1) & (SKC_SLOTS - 1);  // SKC_SLOTS == 8192
   u64 cur = tkey[slot];
   for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
     if (cur == MK_EMPTY) {
@@ -246,8 +269,7 @@ __device__ __forceinline__ void skc_insert(u64* tkey, unsigned* tcnt, unsigned* 
   atomicOr(s_overflow, 1u);  // (a plain volatile LDS store here trips a gfx950 backend assertion in ROCm 7.2)
 }
 
-#define SKC_STAGE 6144                        // keys staged per flush (48 KB)
-#define SKC_PER (SKC_STAGE / SKC_THREADS)     // staged keys per thread per flush
+#define SKC_B 8  // k-mers of a record expanded and probed together
 
 #ifdef MK_STAMP
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
@@ -264,17 +286,16 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
-                                                             int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg) {
+                                                             int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
+                                                             int dflags) {
   __shared__ u64 tkey[SKC_SLOTS];
   __shared__ unsigned tcnt[SKC_SLOTS];
-  __shared__ u64 stage[SKC_STAGE];
-  __shared__ unsigned wsum[SKC_THREADS / 64];
   __shared__ unsigned s_distinct, s_overflow, s_emit;
   for (unsigned i = threadIdx.x; i < SKC_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
   if (threadIdx.x == 0) { s_distinct = 0; s_overflow = 0; s_emit = 0; }
   __syncthreads();
   const int kshift = 64 - 2 * k;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
   u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, npass = 0;
   STAMP(t0);
@@ -337,85 +358,48 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
               recs2[h] = j < n ? src[j] : make_ulonglong2(0, 0);
             }
           }
+          STAMP_ADD(tF, t0);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            if (rb2 + (u64)h * SKC_THREADS >= n || over) break;
+            // ---- one record per thread, expanded 8 k-mers at a time; the 8 first probes are
+            //      issued together, the (rare) collisions and new keys take the slow path
             const ulonglong2 rec = recs2[h];
-            STAMP_ADD(tF, t0);
-            // ---- exclusive scan of the record lengths over the workgroup
-            const unsigned nk = (unsigned)(rec.y & 63);
-            unsigned inc = nk;
+            const int nk = (int)(rec.y & 63);
+            u64 x = rec.x, y = rec.y;
+            for (int base = 0; base < nk; base += SKC_B) {
+              u64 kk[SKC_B], cur[SKC_B];
+              unsigned hh[SKC_B];
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-              const unsigned up = __shfl_up(inc, d);
-              if (lane >= d) inc += up;
-            }
-            if (lane == 63) wsum[wv] = inc;
-            __syncthreads();
-            unsigned pfx = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < SKC_THREADS / 64; ++w) {
-              const unsigned v = wsum[w];
-              if (w < wv) pfx += v;
-              total += v;
-            }
-            const unsigned off = pfx + inc - nk;
-            STAMP_ADD(tA, t0);
-            for (unsigned f = 0; f < total; f += SKC_STAGE) {
-              // ---- expand: this thread's k-mers with staged index in [f, f + SKC_STAGE)
-              {
-                const unsigned g_lo = off > f ? off : f;
-                const unsigned g_hi = (off + nk < f + SKC_STAGE) ? off + nk : f + SKC_STAGE;
-                const unsigned i_lo = g_lo < g_hi ? g_lo - off : 0u;
-                const unsigned i_hi = g_lo < g_hi ? g_hi - off : 0u;
-                if (i_lo < i_hi) {
-                  u64 x = rec.x, y = rec.y;
-                  if (i_lo) {
-                    const unsigned sh = 2 * i_lo;  // 2..60
-                    x = (x << sh) | (y >> (64 - sh));
-                    y <<= sh;
-                  }
-                  unsigned g = off + i_lo - f;
-                  for (unsigned i = i_lo; i < i_hi; ++i, ++g) {
-                    stage[skc_swz(g)] = x >> kshift;
-                    x = (x << 2) | (y >> 62);
-                    y <<= 2;
-                  }
-                }
+              for (int u = 0; u < SKC_B; ++u) {
+                kk[u] = (base + u < nk) ? (x >> kshift) : MK_EMPTY;
+                if (base + u < nk && kk[u] == MK_EMPTY) side_pass += side_done ? 0 : 1;
+                x = (x << 2) | (y >> 62);
+                y <<= 2;
               }
-              __syncthreads();
-              STAMP_ADD(tB, t0);
-              // ---- insert: SKC_PER staged keys per thread, first probes issued together
-              {
-                const unsigned cntk = total - f < SKC_STAGE ? total - f : SKC_STAGE;
-                u64 kk[SKC_PER], cur[SKC_PER];
-                unsigned hh[SKC_PER];
 #pragma unroll
-                for (int u = 0; u < SKC_PER; ++u) {
-                  const unsigned g = threadIdx.x + u * SKC_THREADS;
-                  kk[u] = g < cntk ? stage[skc_swz(g)] : MK_EMPTY;
-                  if (g < cntk && kk[u] == MK_EMPTY) side_pass += side_done ? 0 : 1;
-                }
-#pragma unroll
-                for (int u = 0; u < SKC_PER; ++u) {
-                  hh[u] = skc_hash(kk[u]);
-                  if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) kk[u] = MK_EMPTY;
-                }
-#pragma unroll
-                for (int u = 0; u < SKC_PER; ++u) cur[u] = tkey[hh[u] >> 19];
-#pragma unroll
-                for (int u = 0; u < SKC_PER; ++u) {
-                  if (kk[u] == MK_EMPTY) continue;
-                  const unsigned slot = hh[u] >> 19;
-                  if (cur[u] == kk[u]) atomicAdd(&tcnt[slot], 1u);
-                  else skc_insert(tkey, tcnt, &s_overflow, kk[u], hh[u]);
-                }
+              for (int u = 0; u < SKC_B; ++u) {
+                hh[u] = skc_hash(kk[u]);
+                if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) kk[u] = MK_EMPTY;
               }
-              __syncthreads();
-              STAMP_ADD(tC, t0);
-              if (s_overflow) { over = true; break; }
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u) cur[u] = tkey[hh[u] >> 19];
+              // claims of empty home slots: all compare-and-swaps of the batch in flight together
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u)
+                if (kk[u] != MK_EMPTY && cur[u] == MK_EMPTY) {
+                  cur[u] = atomicCAS(&tkey[hh[u] >> 19], MK_EMPTY, kk[u]);
+                  if (cur[u] == MK_EMPTY) cur[u] = kk[u];
+                }
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u) {
+                if (kk[u] == MK_EMPTY) continue;
+                if (cur[u] == kk[u]) atomicAdd(&tcnt[hh[u] >> 19], 1u);
+                else skc_probe(tkey, tcnt, &s_overflow, kk[u], hh[u]);  // home slot holds another key
+              }
             }
           }
+          STAMP_ADD(tC, t0);
+          if (*(volatile unsigned*)&s_overflow) over = true;  // hint only; decided after the barrier below
         }
         first_pass = false;
         __syncthreads();
@@ -526,7 +510,8 @@ static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, u64* his
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const size_t threads = div_up(seq_len, SK_R), tiles = div_up(threads, SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
-  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(SK_HIST_THREADS), 0, c->stream,
+  // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end
+  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads);
   mk_launch_part_scan(c, hist, start, cursor, p1_log2);
   hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
@@ -548,8 +533,12 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= 13) p1_log2 = v; }
   c->p1_log2 = p1_log2;
   const size_t p1 = (size_t)1 << p1_log2;
+  // Runs are cut into records of at most SK_NKMAX windows: the count kernel expands one record per
+  // thread, SKC_B k-mers per round, so short uniform records keep its lanes busy (measured: 31 ->
+  // 8 trades 1.5x more records for 2.7x fewer expansion rounds).
   int nkmax = 62 - k;
-  if (nkmax > 31) nkmax = 31;
+  if (nkmax > SK_NKMAX) nkmax = SK_NKMAX;
+  if (const char* e = getenv("MK_NKMAX")) { int v = atoi(e); if (v >= 1 && v <= 31 && v <= 62 - k) nkmax = v; }
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   // worst case one record per window
@@ -588,7 +577,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
 #endif
     hipLaunchKernelGGL(mk_sk_count_k, dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p,
                        (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                       (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf);
+                       (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf,
+                       getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0);
   }
   mk_prof_end(c);
 #ifdef MK_STAMP
