@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--reads", type=int, default=READS, help="reads per rank (default: the BASELINE workload)")
     ap.add_argument("--k", type=int, default=K)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "2")),
+                    help="engine contexts (HIP streams) per GPU; chunks are dealt round-robin and counted "
+                         "concurrently, the tables are merged on the device at the end of the step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,17 +113,35 @@ def main():
     bases_rank = args.reads * READ_LEN
     windows_rank = args.reads * (READ_LEN - k + 1)
 
-    ctx = native.Counter(k, native.ALPHABET_NT2, device=local)
+    from concurrent.futures import ThreadPoolExecutor
+    nctx = max(1, args.contexts)
+    ctxs = [native.Counter(k, native.ALPHABET_NT2, device=local) for _ in range(nctx)]
+    ctx = ctxs[0]
+    pool = ThreadPoolExecutor(nctx) if nctx > 1 else None
     key_bits = 2 * k
     out_cap = 2 * GENOME + 1024  # distinct forward-strand k-mers of both strands, upper bound
     out_keys = torch.empty(out_cap, dtype=torch.int64, device=dev)
     out_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev)
+    tmp_keys = torch.empty(out_cap, dtype=torch.int64, device=dev) if nctx > 1 else None
+    tmp_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev) if nctx > 1 else None
     base_ptr = text.data_ptr()
+    chunks = list(zip(offs[:-1], offs[1:]))
+
+    def count_share(i):
+        c = ctxs[i]
+        c.reset()
+        for a, b in chunks[i::nctx]:  # every chunk is filtered on its own (the per-chunk -c rule)
+            c.count_device(base_ptr + a, b - a, MIN_COUNT)
 
     def step():
-        ctx.reset()
-        for a, b in zip(offs[:-1], offs[1:]):
-            ctx.count_device(base_ptr + a, b - a, MIN_COUNT)
+        if pool is None:
+            count_share(0)
+        else:
+            list(pool.map(count_share, range(nctx)))
+            for c in ctxs[1:]:  # sum the other contexts' survivors into context 0, on the device
+                n = c.export_pairs_device(tmp_keys.data_ptr(), tmp_cnts.data_ptr(), out_cap)
+                if n:
+                    ctx.import_pairs_device(tmp_keys.data_ptr(), tmp_cnts.data_ptr(), n)
         if world > 1:
             merge_ranks(ctx, key_bits, device=dev)
         return ctx.export_pairs_device(out_keys.data_ptr(), out_cnts.data_ptr(), out_cap)
@@ -132,8 +153,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.reset_stats()
-    ctx.set_profiling(True)
+    for c in ctxs:
+        c.reset_stats()
+        c.set_profiling(True)
     fence()
     t0 = time.perf_counter()
     rows = 0
@@ -141,8 +163,14 @@ def main():
         rows = step()
     fence()
     dt = time.perf_counter() - t0
-    st = ctx.stats()
-    ctx.set_profiling(False)
+    stats = [c.stats() for c in ctxs]
+    for c in ctxs:
+        c.set_profiling(False)
+    st = dict(stats[0])
+    for other in stats[1:]:  # totals over the contexts of this GPU
+        for key, val in other.items():
+            if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct"):
+                st[key] += val
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     r = torch.tensor([rows], dtype=torch.int64, device=dev)
@@ -174,7 +202,7 @@ def main():
             "config": {"workload": "S2: %d reads x %d bp per GPU from a %d bp genome, k=%d, -c %d, -s %d (%d chunks), "
                                    "forward-strand keys" % (args.reads, READ_LEN, GENOME, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1),
                        "reads_per_gpu": args.reads, "read_len": READ_LEN, "k": k, "min_count": MIN_COUNT,
-                       "chunk_mib": CHUNK_MIB, "chunks": len(offs) - 1, "mode": st["mode_name"],
+                       "chunk_mib": CHUNK_MIB, "chunks": len(offs) - 1, "mode": st["mode_name"], "contexts_per_gpu": nctx,
                        "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
             "distinct_kmers_per_s": total_rows * args.steps / dt,
             "rows": total_rows,

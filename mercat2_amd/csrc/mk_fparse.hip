@@ -169,15 +169,21 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
   const size_t lo = (size_t)threadIdx.x * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
   unsigned e0 = 0, e1 = 1, has = 0;  // running map of this thread's range
   u64 c0 = 0, c1 = 0;
-  for (size_t w = lo; w < hi; ++w) {
-    const FpEntry en = entries[w];
-    const unsigned wnl = en.a & 1u, wx0 = (en.a >> 1) & 1u;
-    const unsigned k0 = en.b & 0xFFFFu, k1 = en.b >> 16;
-    c0 += e0 ? k1 : k0;
-    c1 += e1 ? k1 : k0;
-    e0 = wnl ? wx0 : (e0 | wx0);
-    e1 = wnl ? wx0 : (e1 | wx0);
-    has |= wnl;
+  for (size_t w0 = lo; w0 < hi; w0 += 8) {
+    FpEntry en[8];  // 8 independent loads in flight, then the (serial) state update
+#pragma unroll
+    for (int i = 0; i < 8; ++i) en[i] = (w0 + i < hi) ? entries[w0 + i] : FpEntry{0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (w0 + i >= hi) break;
+      const unsigned wnl = en[i].a & 1u, wx0 = (en[i].a >> 1) & 1u;
+      const unsigned k0 = en[i].b & 0xFFFFu, k1 = en[i].b >> 16;
+      c0 += e0 ? k1 : k0;
+      c1 += e1 ? k1 : k0;
+      e0 = wnl ? wx0 : (e0 | wx0);
+      e1 = wnl ? wx0 : (e1 | wx0);
+      has |= wnl;
+    }
   }
   t_nl[threadIdx.x] = (unsigned char)has;
   t_e0[threadIdx.x] = (unsigned char)e0;
@@ -199,13 +205,19 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
   __syncthreads();
   unsigned q = in_st[threadIdx.x];
   u64 off = in_off[threadIdx.x];
-  for (size_t w = lo; w < hi; ++w) {
-    const FpEntry en = entries[w];
-    scan[w].off = off;
-    scan[w].st = q;
-    const unsigned wnl = en.a & 1u, wx0 = (en.a >> 1) & 1u;
-    off += q ? (en.b >> 16) : (en.b & 0xFFFFu);
-    q = wnl ? wx0 : (q | wx0);
+  for (size_t w0 = lo; w0 < hi; w0 += 8) {
+    FpEntry en[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) en[i] = (w0 + i < hi) ? entries[w0 + i] : FpEntry{0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (w0 + i >= hi) break;
+      scan[w0 + i].off = off;
+      scan[w0 + i].st = q;
+      const unsigned wnl = en[i].a & 1u, wx0 = (en[i].a >> 1) & 1u;
+      off += q ? (en[i].b >> 16) : (en[i].b & 0xFFFFu);
+      q = wnl ? wx0 : (q | wx0);
+    }
   }
 }
 

@@ -306,23 +306,42 @@ int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_co
 
 // --------------------------------------------------------------------------------- compact
 // Occupied slots of a table -> (keys, counts) in arbitrary order; *cursor counts them.
-__global__ void mk_compact_k(const MkSlot* __restrict__ t, size_t slots, u64* __restrict__ keys, u64* __restrict__ cnts,
-                             size_t cap, u64* __restrict__ cursor) {
-  // grid-stride with a wave-uniform trip count so that the ballot below sees whole waves
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  const size_t rounds = (slots + stride - 1) / stride;
+// Each workgroup owns a contiguous slice: pass 1 counts its rows, ONE cursor atomic reserves the
+// output range, pass 2 (slice is L2-hot) places the rows with a wave-aggregated LDS cursor.
+__global__ __launch_bounds__(256) void mk_compact_k(const MkSlot* __restrict__ t, size_t slots, u64* __restrict__ keys,
+                                                    u64* __restrict__ cnts, size_t cap, u64* __restrict__ cursor) {
+  __shared__ unsigned s_n;
+  __shared__ u64 s_base;
+  const size_t per = (slots + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < slots ? lo + per : slots;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  unsigned mine = 0;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const ulonglong2 s = reinterpret_cast<const ulonglong2*>(t)[i];
+    mine += (s.x != MK_EMPTY && s.y != 0) ? 1u : 0u;
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_base = s_n ? atomicAdd(cursor, (u64)s_n) : 0ull;
+    s_n = 0;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63;
+  const size_t rounds = (hi > lo ? hi - lo + blockDim.x - 1 : 0) / blockDim.x;
   for (size_t r = 0; r < rounds; ++r) {
-    const size_t i = r * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = lo + r * blockDim.x + threadIdx.x;
     ulonglong2 s = make_ulonglong2(MK_EMPTY, 0);
-    if (i < slots) s = reinterpret_cast<const ulonglong2*>(t)[i];
+    if (i < hi) s = reinterpret_cast<const ulonglong2*>(t)[i];
     const bool keep = s.x != MK_EMPTY && s.y != 0;
     const u64 m = __ballot(keep);
-    if (m) {  // one cursor atomic per wave, not per row
-      u64 at = 0;
-      if (lane == 0) at = atomicAdd(cursor, (u64)__popcll(m));
-      at = __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1));
-      if (keep && at < cap) { keys[at] = s.x; cnts[at] = s.y; }
+    if (m) {
+      unsigned at = 0;
+      if (lane == 0) at = atomicAdd(&s_n, (unsigned)__popcll(m));
+      const u64 pos = s_base + __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1));
+      if (keep && pos < cap) { keys[pos] = s.x; cnts[pos] = s.y; }
     }
   }
 }
