@@ -31,7 +31,7 @@
 #define SK_NKMAX 8              // windows per record (<= 62 - k)
 #define SK_HIST_THREADS 256
 #define SK_SCAT_THREADS 1024
-#define SK_SCAT_SUBT 4
+#define SK_SCAT_SUBT 1
 #define SK_MAX_P1 8192
 #define SKC_SLOTS 8192
 #define SKC_LOADCAP (SKC_SLOTS / 2)
@@ -59,11 +59,17 @@ __device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
   return (unsigned)(x >> (64 - 2 * SK_M));
 }
 
-// Walks the thread's 32 windows and calls emit(jstart, nk, minimizer) for every record.
+// Result of analysing a thread's 32 windows: which are valid, where runs start, and the 6-bit
+// minimizer position of every window (packed 10 per word).
+struct SkRuns {
+  unsigned valid, starts;
+  u64 pos[4];
+};
+
 // W = k - SK_M + 1 minimizer candidates per window (compile time: the sliding minimum is a
-// doubling network with static indices). nkmax bounds the run length.
-template <int W, class F>
-__device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, F&& emit) {
+// doubling network with static indices).
+template <int W>
+__device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k) {
   constexpr int NQ = SK_R + W - 1;  // candidate positions 0 .. NQ-1
   unsigned ord[NQ];
   {
@@ -78,51 +84,59 @@ __device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int
       ord[q] = (sk_order_hash(mm) & ~63u) | (unsigned)q;
     }
   }
-  // sliding minimum over W consecutive candidates: doubling
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;
 #pragma unroll
   for (int step = 1; step < P; step <<= 1) {
 #pragma unroll
     for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
   }
-  // Pass 1 (static, branch-free): which windows are valid, where each window's minimizer sits,
-  // and where a new run starts (first valid window, minimizer moved, or previous window invalid).
+  // static, branch-free: valid windows, minimizer positions, run starts (first valid window,
+  // minimizer moved, or previous window invalid)
   const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
-  unsigned valid = 0, starts = 0;
-  u64 pos_a = 0, pos_b = 0, pos_c = 0, pos_d = 0;  // 6-bit minimizer positions of windows 0-9, 10-19, 20-29, 30-31
-  unsigned prev_pos = 64;                   // impossible position: window 0 always starts a run
+  SkRuns r;
+  r.valid = 0;
+  r.starts = 0;
+  r.pos[0] = r.pos[1] = r.pos[2] = r.pos[3] = 0;
+  unsigned prev_pos = 64;  // impossible position: window 0 always starts a run
 #pragma unroll
   for (int j = 0; j < SK_R; ++j) {
     const bool ok = ((badw >> j) & kmask) == 0;
     const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
-    valid |= ok ? (1u << j) : 0u;
-    starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
+    r.valid |= ok ? (1u << j) : 0u;
+    r.starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
     prev_pos = ok ? best : 64u;
-    if (j < 10) pos_a |= (u64)best << (6 * j);
-    else if (j < 20) pos_b |= (u64)best << (6 * (j - 10));
-    else if (j < 30) pos_c |= (u64)best << (6 * (j - 20));
-    else pos_d |= (u64)best << (6 * (j - 30));
+    r.pos[j / 10] |= (u64)best << (6 * (j % 10));
   }
-  // Pass 2 (dynamic, one iteration per run): a run ends at the next start, the next invalid
-  // window, the end of the thread's span, or after nkmax windows.
-  unsigned todo = starts;
+  return r;
+}
+
+// One iteration per run: a run ends at the next start, the next invalid window or the end of the
+// thread's span; runs longer than nkmax windows are cut (same minimizer, same bucket).
+template <class F>
+__device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkmax, F&& emit) {
+  unsigned todo = r.starts;
   while (todo) {
     const int j = __ffs(todo) - 1;
     todo &= todo - 1;
-    // windows j.. stay in the run while valid and not a start
-    const unsigned stop = (starts | ~valid) & ~((2u << j) - 1);  // bits above j that end the run
+    const unsigned stop = (r.starts | ~r.valid) & ~((2u << j) - 1);  // bits above j that end the run
     int nk = (stop ? (__ffs(stop) - 1) : SK_R) - j;
-    const u64 pw = j < 10 ? pos_a : (j < 20 ? pos_b : (j < 30 ? pos_c : pos_d));
+    const u64 pw = j < 10 ? r.pos[0] : (j < 20 ? r.pos[1] : (j < 30 ? r.pos[2] : r.pos[3]));
     const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
     const unsigned mm = sk_mmer(w0, w1, (int)best);
     int at = j;
-    while (nk > 0) {  // runs longer than a record holds are cut (same minimizer, same bucket)
+    while (nk > 0) {
       const int take = nk < nkmax ? nk : nkmax;
       emit(at, take, mm);
       at += take;
       nk -= take;
     }
   }
+}
+
+template <int W, class F>
+__device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, F&& emit) {
+  const SkRuns r = sk_analyse<W>(w0, w1, badw, k);
+  sk_walk(r, w0, w1, nkmax, emit);
 }
 
 __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart, int nk, int k) {
@@ -187,15 +201,23 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#pragma unroll 1
+    // pass 1: analyse every sub-tile once (kept in registers for pass 2) and size the runs
+    SkRuns runs[SK_SCAT_SUBT];
+    u64 ww0[SK_SCAT_SUBT], ww1[SK_SCAT_SUBT];
+#pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
       const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
       const size_t p0 = t * SK_R;
-      if (p0 >= seq_len) continue;
-      const u64 w0 = codes[t], w1 = codes[t + 1];
-      const u64 badw = bad_window(bad, p0);
-      sk_for_each_record<W>(w0, w1, badw, k, nkmax,
-                            [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+      runs[st].valid = 0;
+      runs[st].starts = 0;
+      ww0[st] = ww1[st] = 0;
+      if (p0 < seq_len) {
+        ww0[st] = codes[t];
+        ww1[st] = codes[t + 1];
+        runs[st] = sk_analyse<W>(ww0[st], ww1[st], bad_window(bad, p0), k);
+        sk_walk(runs[st], ww0[st], ww1[st], nkmax,
+                [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+      }
     }
     __syncthreads();
     {
@@ -218,14 +240,11 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
       }
     }
     __syncthreads();
-#pragma unroll 1
+    // pass 2: rank of every record inside its run, store
+#pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
-      const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
-      const size_t p0 = t * SK_R;
-      if (p0 >= seq_len) continue;
-      const u64 w0 = codes[t], w1 = codes[t + 1];
-      const u64 badw = bad_window(bad, p0);
-      sk_for_each_record<W>(w0, w1, badw, k, nkmax, [&](int jstart, int nk, unsigned mm) {
+      const u64 w0 = ww0[st], w1 = ww1[st];
+      sk_walk(runs[st], w0, w1, nkmax, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
         part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk_make_record(w0, w1, jstart, nk, k);
       });
