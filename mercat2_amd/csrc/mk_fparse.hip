@@ -35,33 +35,41 @@ struct FpEntry {  // per wave summary / scan result
 };
 
 // Class masks of 16 bytes. Bytes at or beyond `n` behave like newlines (they emit nothing).
-__device__ __forceinline__ void classify16(const uint8_t* __restrict__ raw, size_t pos, size_t n, uint4& v, unsigned& nl,
-                                           unsigned& gt, unsigned& st, unsigned& low, unsigned& hi) {
+__device__ __forceinline__ uint4 classify16(const uint8_t* __restrict__ raw, size_t pos, size_t n, unsigned& nl,
+                                            unsigned& gt, unsigned& st, unsigned& low, unsigned& hi) {
+  uint4 v;
   if (pos + 16 <= n) {
     v = *reinterpret_cast<const uint4*>(raw + pos);
   } else {
-    unsigned w[4] = {0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au};
-    for (int j = 0; j < 16; ++j)
-      if (pos + j < n) w[j >> 2] = (w[j >> 2] & ~(0xFFu << (8 * (j & 3)))) | ((unsigned)raw[pos + j] << (8 * (j & 3)));
-    v = make_uint4(w[0], w[1], w[2], w[3]);
+    unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // static indexing only (no scratch): bytes past n read as '\n'
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const unsigned c = (pos + j < n) ? (unsigned)raw[pos + j] : 10u;
+      const unsigned sh = 8 * (j & 3);
+      if (j < 4) w0 |= c << sh; else if (j < 8) w1 |= c << sh; else if (j < 12) w2 |= c << sh; else w3 |= c << sh;
+    }
+    v = make_uint4(w0, w1, w2, w3);
   }
-  const unsigned x[4] = {v.x, v.y, v.z, v.w};
   nl = gt = st = low = 0;
   hi = 0;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    hi += __popc(x[d] & 0x80808080u);
+    const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));  // no array: stays in registers
+    hi += __popc(xd & 0x80808080u);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const unsigned c = (x[d] >> (8 * e)) & 0xFFu;
+      const unsigned c = (xd >> (8 * e)) & 0xFFu;
       const unsigned bit = 1u << (d * 4 + e);
+      // branch-free selects: with `if (...) mask |= bit` hipcc sinks the OR behind a selected
+      // POINTER to the masks and parks all four in scratch memory
       const bool is_nl = (c == 10u) | (c == 13u);
-      if (is_nl) nl |= bit;
-      if (c == 62u) gt |= bit;
-      if (c == 42u) st |= bit;
-      if (c <= 32u && !is_nl) low |= bit;
+      nl |= is_nl ? bit : 0u;
+      gt |= (c == 62u) ? bit : 0u;
+      st |= (c == 42u) ? bit : 0u;
+      low |= (c <= 32u && !is_nl) ? bit : 0u;
     }
   }
+  return v;
 }
 
 // Header mask of one lane given its entry state: carries of (start|~NL) + start + hin.
@@ -115,9 +123,8 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
-    uint4 v;
     unsigned nl, gt, st, low, hi;
-    classify16(raw, pos, n, v, nl, gt, st, low, hi);
+    (void)classify16(raw, pos, n, nl, gt, st, low, hi);
     nhi += hi;
     unsigned out, sep, bl, last_nl;
     const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
@@ -161,10 +168,6 @@ struct FpScan {
 // entry state through (or-ed with its own exit0); one with a newline resets it to exit0.
 __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict__ entries, size_t nwaves,
                                                        FpScan* __restrict__ scan, MkChunkInfo* __restrict__ info) {
-  __shared__ unsigned char t_nl[1024], t_e0[1024], t_e1[1024];
-  __shared__ u64 t_c0[1024], t_c1[1024];
-  __shared__ unsigned char in_st[1025];
-  __shared__ u64 in_off[1025];
   const size_t per = (nwaves + 1023) / 1024;
   const size_t lo = (size_t)threadIdx.x * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
   unsigned e0 = 0, e1 = 1, has = 0;  // running map of this thread's range
@@ -185,26 +188,51 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
       has |= wnl;
     }
   }
-  t_nl[threadIdx.x] = (unsigned char)has;
-  t_e0[threadIdx.x] = (unsigned char)e0;
-  t_e1[threadIdx.x] = (unsigned char)e1;
-  t_c0[threadIdx.x] = c0;
-  t_c1[threadIdx.x] = c1;
+  // ---- entry state of every thread's range: the same carry chain as inside the parser
+  //      (generate = range ends in a header whatever its entry, propagate = range has no newline)
+  __shared__ unsigned long long w_G[16], w_P[16];
+  __shared__ unsigned w_cin[16];
+  __shared__ u64 w_cnt[16];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 G = __ballot(e0 != 0), P = __ballot(has == 0);
+  if (lane == 0) { w_G[wv] = G; w_P[wv] = P; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned q = 0;  // the chunk starts outside any header
-    u64 off = 0;
-    for (int t = 0; t < 1024; ++t) {
-      in_st[t] = (unsigned char)q;
-      in_off[t] = off;
-      off += q ? t_c1[t] : t_c0[t];
-      q = q ? t_e1[t] : t_e0[t];
+    unsigned cin = 0;  // the chunk starts outside any header
+    for (int w = 0; w < 16; ++w) {
+      w_cin[w] = cin;
+      const u64 A = w_G[w] | w_P[w], B = w_G[w];
+      const u64 sum = A + B + cin;
+      const u64 CI = sum ^ A ^ B;
+      cin = (unsigned)((w_G[w] >> 63) | ((w_P[w] >> 63) & (CI >> 63))) & 1u;  // carry out of lane 63
     }
-    info->seq_len = off;
   }
   __syncthreads();
-  unsigned q = in_st[threadIdx.x];
-  u64 off = in_off[threadIdx.x];
+  unsigned q;
+  {
+    const u64 A = G | P, B = G;
+    const u64 CI = (A + B + (u64)w_cin[wv]) ^ A ^ B;
+    q = (unsigned)(CI >> lane) & 1u;
+  }
+  // ---- output offsets: prefix sum of the count that matches each range's entry state
+  const u64 mine = q ? c1 : c0;
+  u64 inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 up = __shfl_up(inc, d);
+    if (lane >= d) inc += up;
+  }
+  if (lane == 63) w_cnt[wv] = inc;
+  __syncthreads();
+  u64 off = inc - mine;
+  u64 total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const u64 v = w_cnt[w];
+    if (w < wv) off += v;
+    total += v;
+  }
+  if (threadIdx.x == 0) info->seq_len = total;
   for (size_t w0 = lo; w0 < hi; w0 += 8) {
     FpEntry en[8];
 #pragma unroll
@@ -240,9 +268,8 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
-    uint4 v;
     unsigned nl, gt, st, low, hi;
-    classify16(raw, pos, n, v, nl, gt, st, low, hi);
+    const uint4 v = classify16(raw, pos, n, nl, gt, st, low, hi);
     unsigned out, sep, bl, last_nl;
     state = wave_step(nl, gt, st, low, prev_nl, state, out, sep, bl, last_nl);
     prev_nl = last_nl;
@@ -255,19 +282,20 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
       if (lane >= d) inc += up;
     }
     unsigned at = shift + filled + inc - cnt;
-    const unsigned x[4] = {v.x, v.y, v.z, v.w};
+#define FP_BYTE(j) ((uint8_t)(((j) < 4 ? v.x : ((j) < 8 ? v.y : ((j) < 12 ? v.z : v.w))) >> (8 * ((j) & 3))))
     if (out == 0xFFFFu && sep == 0) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) lds[at + j] = (uint8_t)(x[j >> 2] >> (8 * (j & 3)));
+      for (int j = 0; j < 16; ++j) lds[at + j] = FP_BYTE(j);
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if ((out >> j) & 1u) {
-          lds[at] = ((sep >> j) & 1u) ? (uint8_t)MK_SEP : (uint8_t)(x[j >> 2] >> (8 * (j & 3)));
+          lds[at] = ((sep >> j) & 1u) ? (uint8_t)MK_SEP : FP_BYTE(j);
           ++at;
         }
       }
     }
+#undef FP_BYTE
     filled += __shfl(inc, 63);
   }
   // ---- write out: LDS offset == destination address (mod 16), so full 16-byte pieces are aligned
