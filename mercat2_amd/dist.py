@@ -47,6 +47,12 @@ def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, grou
     world = dist.get_world_size(group)
     if world == 1:
         return keys, counts
+    dev = keys.device
+    if dev.type != "cpu" and dist.get_backend(group) == "gloo":
+        # gloo moves host memory: stage through the CPU (test / single-GPU rehearsal path; with
+        # backend "nccl" = RCCL the tensors stay on the device and travel over xGMI)
+        rk, rc = exchange_pairs(keys.cpu(), counts.cpu(), key_bits, group)
+        return rk.to(dev), rc.to(dev)
     pts = split_points(keys, key_bits, world)
     send = (pts[1:] - pts[:-1]).to(torch.int64)
     recv = torch.empty_like(send)
