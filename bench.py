@@ -195,6 +195,15 @@ def main():
                        "byref": "mk_count_byref_k"}.get(st["mode_name"], "?")
         if os.environ.get("MK_NO_PARTITION"):
             kernel_name = "mk_count_hash64_k"
+        # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in
+        # separate rocprofv3 runs of this command, gfx950 correction applied: tools/trim_profiles.py)
+        traffic, traffic_src = None, None
+        pmc_file = ROOT / "profiles" / "round1_pmc_traffic.json"
+        if pmc_file.exists() and args.reads == READS and k == K:
+            pmc = json.loads(pmc_file.read_text())
+            if kernel_name in pmc:
+                traffic = pmc[kernel_name]["hbm_bytes_per_launch"]
+                traffic_src = "profiles/round1_pmc_traffic.csv"
         line = {
             "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
@@ -208,7 +217,7 @@ def main():
             "rows": total_rows,
             "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "part", "count", "exotic", "filter", "export")},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "ms_per_launch": ms_launch,
                          "algorithmic_bytes_per_launch": alg_bytes / launches,
                          "stage_ms_per_launch": stage_ms, "stage_achieved": stage_achieved,

@@ -1,0 +1,52 @@
+"""Turn the rocprofv3 outputs of tools/make_profiles.sh (gpurun_out/) into the small committed
+summaries under profiles/."""
+import collections, csv, glob, json, re, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "round1"
+
+def short(name):
+    m = re.search(r"(mk_\w+|radix_sort_onesweep_\w+|__amd_rocclr_\w+)", name)
+    return m.group(1) if m else name[:40]
+
+for ctx in (2, 1):
+    files = glob.glob("gpurun_out/prof_%s_ctx%d/*/*kernel_stats.csv" % (tag, ctx))
+    if not files:
+        continue
+    rows = list(csv.DictReader(open(files[0])))
+    with open("profiles/%s_kernel_stats_ctx%d.csv" % (rnd, ctx), "w") as w:
+        w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --contexts %d\n" % ctx)
+        w.write("# S2 workload (10M x 150bp, k=31, -c 10, 16 chunks); 4 passes incl. warmup; kernel names trimmed\n")
+        w.write("name,calls,total_ms,avg_us,pct\n")
+        for r in rows:
+            w.write("%s,%s,%.3f,%.1f,%s\n" % (short(r["Name"]), r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    line = [l for l in open("gpurun_out/prof_%s_ctx%d.log" % (tag, ctx)) if l.startswith('{"metric"')]
+    if line:
+        open("profiles/%s_bench_under_rocprof_ctx%d.json" % (rnd, ctx), "w").write(line[-1])
+
+pmc = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    files = glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c))
+    if not files:
+        continue
+    agg = collections.defaultdict(lambda: [0, 0.0, 0])
+    for r in csv.DictReader(open(files[0])):
+        a = agg[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+        a[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    pmc[c] = agg
+if pmc:
+    out = {}
+    with open("profiles/%s_pmc_traffic.csv" % rnd, "w") as w:
+        w.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --contexts 1\n")
+        w.write("# counters in KB per launch. hbm_bytes_per_launch applies the gfx950 correction of MI355X_MICROARCH.md (HBM section):\n")
+        w.write("#   FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled; WRITE_SIZE as read.\n")
+        w.write("name,launches,fetch_kb,write_kb,hbm_bytes_per_launch,avg_us\n")
+        for n, (calls, v, t) in sorted(pmc["FETCH_SIZE"].items(), key=lambda x: -x[1][2]):
+            wv = pmc.get("WRITE_SIZE", {}).get(n, [1, 0.0, 0])
+            f_kb, w_kb = v / calls, wv[1] / max(1, wv[0])
+            hbm = (2 * f_kb + w_kb) * 1024
+            out[n] = {"fetch_kb": f_kb, "write_kb": w_kb, "hbm_bytes_per_launch": hbm, "launches": calls}
+            w.write("%s,%d,%.0f,%.0f,%.0f,%.1f\n" % (n, calls, f_kb, w_kb, hbm, t / calls / 1e3))
+    json.dump(out, open("profiles/%s_pmc_traffic.json" % rnd, "w"), indent=1)
+print("ok")
