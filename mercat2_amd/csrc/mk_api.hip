@@ -284,8 +284,9 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   }
   for (int attempt = 0; attempt < 2; ++attempt) {
     const bool fast = c->use_fast_parse && attempt == 0;
-    if ((rc = fast ? mk_launch_fparse(c, d_raw, n) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
-    if (packed && (rc = mk_launch_pack(c, n)) != MK_OK) return rc;
+    const bool fused = fast && packed && c->alphabet == MK_ALPHABET_NT2;  // the nt pack rides on the parser's LDS image
+    if ((rc = fast ? mk_launch_fparse(c, d_raw, n, fused) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
+    if (packed && !fused && (rc = mk_launch_pack(c, n)) != MK_OK) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
     if (!fast || !c->h_info->parse_fallback) break;
     // a blank inside a sequence line: the general transducer handles strip() exactly

@@ -251,8 +251,10 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
 
 __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __restrict__ raw, size_t n, size_t nwaves,
                                                              FpScan* __restrict__ scan, uint8_t* __restrict__ seq,
-                                                             MkChunkInfo* __restrict__ info) {
-  __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][FP_WAVE_BYTES + 32];
+                                                             MkChunkInfo* __restrict__ info, u64* __restrict__ codes,
+                                                             u64* __restrict__ bad) {
+  // 64 bytes of slack on both sides: the fused pack reads whole 64-symbol words around the ends
+  __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][64 + FP_WAVE_BYTES + 32 + 64];
   const int wv = threadIdx.x >> 6;
   const size_t wave = (size_t)blockIdx.x * FP_WAVES + wv;
   if (wave >= nwaves) return;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   const size_t base = wave * FP_WAVE_BYTES;
   const FpScan sc = scan[wave];
   const unsigned shift = (unsigned)(sc.off & 15);
-  uint8_t* __restrict__ lds = stage[wv];
+  uint8_t* __restrict__ lds = stage[wv] + 64;
   unsigned prev_nl = (base == 0) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
   unsigned state = sc.st;
   unsigned filled = 0;   // bytes emitted so far by this wave
@@ -312,12 +314,60 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
       for (unsigned j = lo; j < hi; ++j) dst[j] = lds[j];
     }
   }
+  // ---- fused 2-bit pack (nt): the wave's symbols are still in LDS, so the packed words and the
+  //      bad bitmap are produced here instead of re-reading seq (mk_pack.hip layout). Words that
+  //      the wave covers completely are stored; the partial word at either end is OR-ed into the
+  //      zero-initialised arrays (the neighbouring wave ORs its part).
+  if (codes) {
+    const u64 g0 = sc.off, g1 = sc.off + filled;
+    unsigned nbad = 0;
+    for (u64 b = (g0 >> 6) + lane; b < ((g1 + 63) >> 6); b += 64) {
+      const u64 s_lo = b << 6, s_hi = s_lo + 64;
+      const u64 lo = s_lo > g0 ? s_lo : g0, hi = s_hi < g1 ? s_hi : g1;
+      u64 w0 = 0, w1 = 0, bd = 0;
+      // always the 64-byte vector path; symbols of the word outside [lo, hi) (another wave's, or
+      // past the end: whatever the LDS slack holds) are masked off -- no divergent byte loop
+      const u64 in_lo = lo - s_lo, in_n = hi - lo;  // valid symbols: in_lo .. in_lo+in_n-1
+      const u64 inmask = (in_n >= 64 ? ~0ull : ((1ull << in_n) - 1)) << in_lo;
+      const uint4* p = reinterpret_cast<const uint4*>(lds + (long)shift + (long)(s_lo - g0));  // 16-byte aligned
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = p[q];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned ch = (xd >> (8 * e)) & 0xFFu;
+            const int j = q * 16 + d * 4 + e;
+            const bool in = (inmask >> j) & 1ull;
+            const bool ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+            const u64 code = (ok && in) ? (u64)(((ch >> 1) & 3u) ^ ((ch >> 2) & 1u)) : 0ull;
+            if (j < 32) w0 |= code << (62 - 2 * j); else w1 |= code << (62 - 2 * (j - 32));
+            bd |= (!ok && in) ? (1ull << j) : 0ull;
+            nbad += (!ok && in && ch != MK_SEP) ? 1u : 0u;
+          }
+        }
+      }
+      if (in_n == 64) {
+        codes[2 * b] = w0;
+        codes[2 * b + 1] = w1;
+        bad[b] = bd;
+      } else {
+        if (w0) atomicOr(&codes[2 * b], w0);
+        if (w1) atomicOr(&codes[2 * b + 1], w1);
+        if (bd) atomicOr(&bad[b], bd);
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) nbad += __shfl_down(nbad, d);
+    if (lane == 0 && nbad) atomicAdd(&info->bad_symbols, (u64)nbad);
+  }
   for (int d = 32; d > 0; d >>= 1) nsym += __shfl_down(nsym, d);
   if (lane == 0) scan[wave].pad = nsym;  // summed by mk_fparse_total (no hot atomic)
 }
 
 __global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict__ scan, size_t nwaves,
-                                                        MkChunkInfo* __restrict__ info) {
+                                                        MkChunkInfo* __restrict__ info, u64* __restrict__ bad) {
   __shared__ u64 part[16];
   u64 s = 0;
   for (size_t w = threadIdx.x; w < nwaves; w += 1024) s += scan[w].pad;
@@ -328,11 +378,27 @@ __global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict
     u64 t = 0;
     for (int i = 0; i < 16; ++i) t += part[i];
     info->symbols = t;
+    if (bad) {  // symbols past the end of seq are "bad" (fused pack): tail of the last word + 3 more words
+      const u64 n = info->seq_len;
+      if (n & 63) atomicOr(&bad[n >> 6], ~0ull << (n & 63));
+      const u64 w = (n + 63) >> 6;
+      bad[w] = ~0ull;
+      bad[w + 1] = ~0ull;
+      bad[w + 2] = ~0ull;
+    }
   }
 }
 
 // Returns MK_OK after enqueueing; info->parse_fallback != 0 afterwards means "re-parse with the general kernels".
-int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n) {
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n, bool fuse_pack_nt) {
+  u64* codes = fuse_pack_nt ? (u64*)c->codes.p : nullptr;
+  u64* bad = fuse_pack_nt ? (u64*)c->bad.p : nullptr;
+  if (fuse_pack_nt) {  // partial words are OR-ed in: start from zero (padding words included)
+    const size_t bad_words = n / 64 + 4;
+    MK_HIP(hipMemsetAsync(c->codes.p, 0, 2 * bad_words * sizeof(u64), c->stream));
+    MK_HIP(hipMemsetAsync(c->bad.p, 0, bad_words * sizeof(u64), c->stream));
+    if (n == 0) MK_HIP(hipMemsetAsync(c->bad.p, 0xFF, 4 * sizeof(u64), c->stream));
+  }
   if (n == 0) return MK_OK;
   const size_t nwaves = (n + FP_WAVE_BYTES - 1) / FP_WAVE_BYTES;
   const size_t e_bytes = (nwaves * sizeof(FpEntry) + 15) & ~(size_t)15;
@@ -346,8 +412,8 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n) {
   hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, entries, info);
   hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info);
   hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, scan,
-                     (uint8_t*)c->seq.p, info);
-  hipLaunchKernelGGL(mk_fparse_total, dim3(1), dim3(1024), 0, c->stream, (const FpScan*)scan, nwaves, info);
+                     (uint8_t*)c->seq.p, info, codes, bad);
+  hipLaunchKernelGGL(mk_fparse_total, dim3(1), dim3(1024), 0, c->stream, (const FpScan*)scan, nwaves, info, bad);
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
   return MK_OK;

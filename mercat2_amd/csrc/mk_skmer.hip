@@ -272,9 +272,10 @@ __device__ __forceinline__ unsigned skc_hash(u64 key) {
 }
 
 #define SKC_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
-// Linear probing from the slot after the home slot (the caller has seen the home slot taken by another key).
+// Linear probing from slot home+SKC_STEPS on (the caller has seen the first SKC_STEPS slots taken by other keys).
+#define SKC_STEPS 1  // batched probe steps before the serial loop
 __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
-  unsigned slot = ((h >> 19) + 1) & (SKC_SLOTS - 1);  // SKC_SLOTS == 8192
+  unsigned slot = ((h >> 19) + SKC_STEPS) & (SKC_SLOTS - 1);  // SKC_SLOTS == 8192
   u64 cur = tkey[slot];
   for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
     if (cur == MK_EMPTY) {
@@ -309,10 +310,12 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
                                                              int dflags) {
   __shared__ u64 tkey[SKC_SLOTS];
   __shared__ unsigned tcnt[SKC_SLOTS];
-  __shared__ unsigned s_distinct, s_overflow, s_emit;
+  // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
+  __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   for (unsigned i = threadIdx.x; i < SKC_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
-  if (threadIdx.x == 0) { s_distinct = 0; s_overflow = 0; s_emit = 0; }
+  if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
   __syncthreads();
+  unsigned par = 0;
   const int kshift = 64 - 2 * k;
   const int lane = threadIdx.x & 63;
   u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
@@ -354,6 +357,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
         const double expect = (double)n * nk_hint / (dup_hint > 1.0 ? dup_hint : 1.0);
         while (s0 < SKC_SUB_BITS && expect / (double)(1u << s0) > (double)SKC_TARGET) ++s0;
         if ((double)n * 31.0 <= (double)SKC_LOADCAP) s0 = 0;
+        if (dflags & 16) s0 = 0;  // (timing experiments only)
       }
       int s = s0;
       unsigned idx = 0;
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
         const unsigned sel_shift = SKC_SUB_BITS - s;
         side_pass = 0;  // the all-ones key (32 x 'T') is counted aside, once per bucket
         bool over = false;
+        unsigned* const ovf = &s_overflow[par];
         for (u64 rb2 = 0; rb2 < n && !over; rb2 += 2 * SKC_THREADS) {
           ulonglong2 recs2[2];
           if (first_pass && rb2 == 0) {
@@ -400,31 +405,41 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
                 hh[u] = skc_hash(kk[u]);
                 if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) kk[u] = MK_EMPTY;
               }
+              // up to SKC_STEPS probe steps with the whole batch in flight: reads of slot home+step,
+              // then the compare-and-swaps of the empty ones, then the adds. A key is done once its
+              // slot holds it; what is still unresolved after the last step (a few %) probes serially.
 #pragma unroll
-              for (int u = 0; u < SKC_B; ++u) cur[u] = tkey[hh[u] >> 19];
-              // claims of empty home slots: all compare-and-swaps of the batch in flight together
+              for (int step = 0; step < SKC_STEPS; ++step) {
+#pragma unroll
+                for (int u = 0; u < SKC_B; ++u)
+                  if (kk[u] != MK_EMPTY) cur[u] = tkey[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)];
+#pragma unroll
+                for (int u = 0; u < SKC_B; ++u)
+                  if (kk[u] != MK_EMPTY && cur[u] == MK_EMPTY) {
+                    cur[u] = atomicCAS(&tkey[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)], MK_EMPTY, kk[u]);
+                    if (cur[u] == MK_EMPTY) cur[u] = kk[u];
+                  }
+#pragma unroll
+                for (int u = 0; u < SKC_B; ++u)
+                  if (kk[u] != MK_EMPTY && cur[u] == kk[u]) {
+                    atomicAdd(&tcnt[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)], 1u);
+                    kk[u] = MK_EMPTY;  // resolved
+                  }
+              }
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u)
-                if (kk[u] != MK_EMPTY && cur[u] == MK_EMPTY) {
-                  cur[u] = atomicCAS(&tkey[hh[u] >> 19], MK_EMPTY, kk[u]);
-                  if (cur[u] == MK_EMPTY) cur[u] = kk[u];
-                }
-#pragma unroll
-              for (int u = 0; u < SKC_B; ++u) {
-                if (kk[u] == MK_EMPTY) continue;
-                if (cur[u] == kk[u]) atomicAdd(&tcnt[hh[u] >> 19], 1u);
-                else skc_probe(tkey, tcnt, &s_overflow, kk[u], hh[u]);  // home slot holds another key
-              }
+                if (kk[u] != MK_EMPTY) skc_probe(tkey, tcnt, ovf, kk[u], hh[u]);
             }
           }
           STAMP_ADD(tC, t0);
-          if (*(volatile unsigned*)&s_overflow) over = true;  // hint only; decided after the barrier below
+          if (*(volatile unsigned*)ovf) over = true;  // hint only; decided after the barrier below
         }
         first_pass = false;
-        __syncthreads();
+        __syncthreads();  // A: every insert of the pass is in the table
         STAMP_ADD(tF, t0);
         ++npass;
-        over = s_overflow != 0;
+        over = s_overflow[par] != 0;
+        if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }  // next pass's set
         // will this be the bucket's last pass? then start loading the next bucket's records now
         bool last = false;
         if (!over) {
@@ -458,9 +473,9 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
             mine += ek[q] != MK_EMPTY;
           }
           for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
-          if (lane == 0 && occ && !over) atomicAdd(&s_distinct, occ);
+          if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
           if (mine) {
-            const unsigned at = emitted + atomicAdd(&s_emit, mine);  // LDS cursor inside the region
+            const unsigned at = emitted + atomicAdd(&s_emit[par], mine);  // LDS cursor inside the region
             unsigned o = 0;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
@@ -471,13 +486,11 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
               }
             }
           }
-          __syncthreads();
-          emitted += s_emit;
-          distinct_total += s_distinct;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { s_distinct = 0; s_overflow = 0; s_emit = 0; }
-        __syncthreads();
+        __syncthreads();  // B: table is clear, counters of this pass are final
+        emitted += s_emit[par];
+        distinct_total += s_distinct[par];
+        par ^= 1;
         STAMP_ADD(tD, t0);
         if (over) {
           if (s >= SKC_SUB_BITS) { ++nerr; break; }
