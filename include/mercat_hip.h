@@ -75,6 +75,11 @@ const char* mk_last_error(const mk_ctx* ctx);
 /* Forget the running (merged) table: start the next sample (run_mercat2's `kmers = dict()`,
  * bin/mercat2.py:117). */
 int mk_reset(mk_ctx* ctx);
+/* Opt-in extension, NOT reference behaviour (the reference counts forward-strand substrings,
+ * lib/mercat2_kmers.py:56-60): with on != 0 every ACGT-only window is counted under
+ * min(kmer, reverse-complement(kmer)).  Windows holding other characters keep their own text.
+ * Nucleotide alphabet only; call before the first chunk of a sample (or right after mk_reset). */
+int mk_set_canonical(mk_ctx* ctx, int on);
 
 /* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */
 int mk_chunk_begin(mk_ctx* ctx);

@@ -203,6 +203,19 @@ extern "C" int mk_reset(mk_ctx* c) {
   return MK_OK;
 }
 
+extern "C" int mk_set_canonical(mk_ctx* c, int on) {
+  if (!c) return MK_ERR_ARG;
+  if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_canonical: only the nucleotide alphabet has a reverse complement"; return MK_ERR_ARG; }
+  if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run_side || c->st.chunks) {
+    if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run_side || c->in_chunk)) {
+      c->err = "mk_set_canonical: the running table already holds rows counted in the other mode (mk_reset first)";
+      return MK_ERR_STATE;
+    }
+  }
+  c->canonical = on ? 1 : 0;
+  return MK_OK;
+}
+
 // ----------------------------------------------------------------------------- chunk feed
 extern "C" int mk_chunk_begin(mk_ctx* c) {
   if (!c) return MK_ERR_ARG;

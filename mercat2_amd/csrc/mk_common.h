@@ -132,6 +132,7 @@ struct mk_ctx {
   double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
   int use_partition = 1;
   int use_fast_parse = 1;
+  int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)
   int use_superkmer = 1;
   int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
   double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk

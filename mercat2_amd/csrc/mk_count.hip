@@ -42,7 +42,7 @@ __device__ __forceinline__ void insert64(MkSlot* __restrict__ table, u64 mask, u
 template <int BITS, int SPW, int WPT>
 __global__ __launch_bounds__(256) void mk_count_hash64_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                          MkChunkInfo* __restrict__ info, MkSlot* __restrict__ table,
-                                                         u64 mask, int k) {
+                                                         u64 mask, int k, int canon) {
   constexpr int R = SPW * WPT;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t p0 = t * R;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void mk_count_hash64_k(const u64* __restrict__
       for (int i = 0; i < WPT; ++i) {
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
-          u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+          u64 key = mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
           if (key == MK_EMPTY) atomicAdd(&info->side, 1ull); else insert64(table, mask, key, 1);
         }
       }
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void mk_count_hash64_k(const u64* __restrict__
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
           if (((badw >> (i * SPW + s)) & kmask) == 0) {
-            u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+            u64 key = mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
             if (key == MK_EMPTY) atomicAdd(&info->side, 1ull); else insert64(table, mask, key, 1);
             ++mine;
           }
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void mk_count_hash64_k(const u64* __restrict__
 template <int BITS, int SPW, int WPT>
 __global__ __launch_bounds__(256) void mk_count_dense_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                         MkChunkInfo* __restrict__ info, u64* __restrict__ bins,
-                                                        unsigned nbins, unsigned copies_log2, int k, size_t nthreads_total) {
+                                                        unsigned nbins, unsigned copies_log2, int k, size_t nthreads_total,
+                                                        int canon) {
   extern __shared__ unsigned hist[];
   constexpr int R = SPW * WPT;
   const unsigned copies = 1u << copies_log2;
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void mk_count_dense_k(const u64* __restrict__ 
 #pragma unroll
       for (int s = 0; s < SPW; ++s) {
         if (((badw >> (i * SPW + s)) & kmask) == 0) {
-          unsigned key = (unsigned)window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+          unsigned key = (unsigned)mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
           atomicAdd(&hist[(key << copies_log2) | my_copy], 1u);
           ++mine;
         }
@@ -221,11 +222,11 @@ int mk_launch_count_hash64(mk_ctx* c, size_t seq_len) {
   if (c->alphabet == MK_ALPHABET_NT2) {
     const size_t threads = div_up(seq_len, 32);
     hipLaunchKernelGGL((mk_count_hash64_k<2, 32, 1>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
-                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k);
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k, c->canonical);
   } else {
     const size_t threads = div_up(seq_len, 36);
     hipLaunchKernelGGL((mk_count_hash64_k<5, 12, 3>), dim3((unsigned)div_up(threads, 256)), dim3(256), 0, c->stream,
-                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k);
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->ctab.p, mask, c->k, c->canonical);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
@@ -246,7 +247,7 @@ int mk_launch_count_dense(mk_ctx* c, size_t seq_len) {
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL((mk_count_dense_k<2, 32, 1>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
                        (const u64*)c->codes.p, (const u64*)c->bad.p, info, (u64*)c->ctab.p, nbins, copies_log2, c->k,
-                       threads);
+                       threads, c->canonical);
   } else {
     const size_t threads = div_up(seq_len, 36);
     size_t blocks = div_up(threads, 256);
@@ -254,7 +255,7 @@ int mk_launch_count_dense(mk_ctx* c, size_t seq_len) {
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((mk_count_dense_k<5, 12, 3>), dim3((unsigned)blocks), dim3(256), lds, c->stream,
                        (const u64*)c->codes.p, (const u64*)c->bad.p, info, (u64*)c->ctab.p, nbins, copies_log2, c->k,
-                       threads);
+                       threads, c->canonical);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());

@@ -27,3 +27,17 @@ __device__ __forceinline__ void wave_add(u64* target, u64 mine) {
   for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(target, mine);
 }
+
+// Reverse complement of a packed nucleotide key (k symbols, 2 bits each, A0 C1 G2 T3: the
+// complement of code c is 3-c, i.e. ~c). Bit-reverse the complemented word, put the two bits
+// of every symbol back in order, and shift the k symbols down.
+__device__ __forceinline__ u64 mk_revcomp2(u64 key, int k) {
+  u64 x = __brevll(~key);
+  x = ((x & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((x & 0x5555555555555555ull) << 1);
+  return x >> (64 - 2 * k);
+}
+__device__ __forceinline__ u64 mk_canon2(u64 key, int k, bool canonical) {
+  if (!canonical) return key;
+  const u64 rc = mk_revcomp2(key, k);
+  return rc < key ? rc : key;
+}

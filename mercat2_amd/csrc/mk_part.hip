@@ -39,7 +39,7 @@ static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 template <int BITS, int SPW, int WPT>
 __global__ __launch_bounds__(PART_THREADS) void mk_part_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
-                                                               int p1_log2, int k, size_t nthreads_total) {
+                                                               int p1_log2, int k, size_t nthreads_total, int canon) {
   __shared__ unsigned lh[PART_MAX_P1];
   constexpr int R = SPW * WPT;
   const unsigned p1 = 1u << p1_log2;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(PART_THREADS) void mk_part_hist_k(const u64* __rest
 #pragma unroll
       for (int s = 0; s < SPW; ++s) {
         if (((badw >> (i * SPW + s)) & kmask) == 0) {
-          const u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+          const u64 key = mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
           ++mine;
           if (key == MK_EMPTY) ++side;
           else atomicAdd(&lh[(unsigned)(mk_mix64(key) >> (64 - p1_log2))], 1u);
@@ -117,7 +117,7 @@ template <int BITS, int SPW, int WPT>
 __global__ __launch_bounds__(SCAT_THREADS) void mk_part_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                   const MkChunkInfo* __restrict__ info,
                                                                   u64* __restrict__ cursor, u64* __restrict__ part,
-                                                                  int p1_log2, int k, size_t ntiles, int dbg) {
+                                                                  int p1_log2, int k, size_t ntiles, int dbg, int canon) {
   __shared__ unsigned lh[PART_MAX_P1];
   __shared__ u64 gbase[PART_MAX_P1];
   constexpr int R = SPW * WPT;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void mk_part_scatter_k(const u64* __r
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
           if (((badw >> (i * SPW + s)) & kmask) == 0) {
-            const u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+            const u64 key = mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
             if (key != MK_EMPTY) atomicAdd(&lh[(unsigned)(mk_mix64(key) >> hshift)], 1u);
           }
         }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void mk_part_scatter_k(const u64* __r
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
           if (((badw >> (i * SPW + s)) & kmask) == 0) {
-            const u64 key = window_key<BITS, SPW>(w[i], w[i + 1], s, k);
+            const u64 key = mk_canon2(window_key<BITS, SPW>(w[i], w[i + 1], s, k), k, BITS == 2 && canon);
             if (key != MK_EMPTY) {
               const unsigned b = (unsigned)(mk_mix64(key) >> hshift);
               const u64 at = gbase[b] + atomicAdd(&lh[b], 1u);
@@ -381,21 +381,21 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     const size_t stiles = div_up(threads, (size_t)SCAT_THREADS * SCAT_SUBT);
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL((mk_part_hist_k<2, 32, 1>), dim3(grid), dim3(PART_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                       (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads);
+                       (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads, c->canonical);
     hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2);
     hipLaunchKernelGGL((mk_part_scatter_k<2, 32, 1>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SCAT_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (u64*)c->part.p, p1_log2,
-                       c->k, stiles, dbg);
+                       c->k, stiles, dbg, c->canonical);
   } else {
     const size_t threads = div_up(seq_len, 36), tiles = div_up(threads, PART_THREADS);
     const size_t stiles = div_up(threads, (size_t)SCAT_THREADS * SCAT_SUBT);
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL((mk_part_hist_k<5, 12, 3>), dim3(grid), dim3(PART_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                       (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads);
+                       (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads, c->canonical);
     hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2);
     hipLaunchKernelGGL((mk_part_scatter_k<5, 12, 3>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SCAT_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (u64*)c->part.p, p1_log2,
-                       c->k, stiles, dbg);
+                       c->k, stiles, dbg, c->canonical);
   }
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);

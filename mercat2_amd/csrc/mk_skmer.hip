@@ -41,12 +41,23 @@
 
 static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
-__device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {  // top 26 bits used for ordering
-  unsigned h = mm * 0x9E3779B1u;
-  h ^= h >> 15;
-  h *= 0x85EBCA77u;
+// Ordering hash: a BIJECTION on the 22-bit 11-mers (odd multiplies and xor-shifts modulo 2^22), so
+// "smallest hash" is a strict total order on 11-mer values: two positions tie only when they hold
+// the same 11-mer, and then either choice names the same minimizer. (The canonical mode relies on
+// this: a window and its reverse complement see the candidates in opposite order.)
+__device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {
+  unsigned h = (mm * 0x2C9277B5u) & SK_MASK;
+  h ^= h >> 11;
+  h = (h * 0x1B873593u) & SK_MASK;
   h ^= h >> 13;
+  h = (h * 0x0019660Du) & SK_MASK;
   return h;
+}
+// 11-mer under which a window is filed: itself, or min(itself, reverse complement) in canonical mode.
+__device__ __forceinline__ unsigned sk_canon_mmer(unsigned mm, bool canon) {
+  if (!canon) return mm;
+  const unsigned rc = (unsigned)mk_revcomp2((u64)mm, SK_M);
+  return rc < mm ? rc : mm;
 }
 __device__ __forceinline__ unsigned sk_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
 
@@ -69,7 +80,7 @@ struct SkRuns {
 // W = k - SK_M + 1 minimizer candidates per window (compile time: the sliding minimum is a
 // doubling network with static indices).
 template <int W>
-__device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k) {
+__device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k, bool canon) {
   constexpr int NQ = SK_R + W - 1;  // candidate positions 0 .. NQ-1
   unsigned ord[NQ];
   {
@@ -81,7 +92,7 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k) {
         const unsigned base = (unsigned)((pos < 32 ? (w0 >> (62 - 2 * pos)) : (w1 >> (62 - 2 * (pos - 32)))) & 3u);
         mm = ((mm << 2) | base) & SK_MASK;
       }
-      ord[q] = (sk_order_hash(mm) & ~63u) | (unsigned)q;
+      ord[q] = (sk_order_hash(sk_canon_mmer(mm, canon)) << 6) | (unsigned)q;
     }
   }
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;
@@ -113,7 +124,7 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k) {
 // One iteration per run: a run ends at the next start, the next invalid window or the end of the
 // thread's span; runs longer than nkmax windows are cut (same minimizer, same bucket).
 template <class F>
-__device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkmax, F&& emit) {
+__device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkmax, bool canon, F&& emit) {
   unsigned todo = r.starts;
   while (todo) {
     const int j = __ffs(todo) - 1;
@@ -122,7 +133,7 @@ __device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkm
     int nk = (stop ? (__ffs(stop) - 1) : SK_R) - j;
     const u64 pw = j < 10 ? r.pos[0] : (j < 20 ? r.pos[1] : (j < 30 ? r.pos[2] : r.pos[3]));
     const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
-    const unsigned mm = sk_mmer(w0, w1, (int)best);
+    const unsigned mm = sk_canon_mmer(sk_mmer(w0, w1, (int)best), canon);
     int at = j;
     while (nk > 0) {
       const int take = nk < nkmax ? nk : nkmax;
@@ -134,9 +145,9 @@ __device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkm
 }
 
 template <int W, class F>
-__device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, F&& emit) {
-  const SkRuns r = sk_analyse<W>(w0, w1, badw, k);
-  sk_walk(r, w0, w1, nkmax, emit);
+__device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, bool canon, F&& emit) {
+  const SkRuns r = sk_analyse<W>(w0, w1, badw, k, canon);
+  sk_walk(r, w0, w1, nkmax, canon, emit);
 }
 
 __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart, int nk, int k) {
@@ -154,7 +165,7 @@ template <int W>
 __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                 MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                 u64* __restrict__ khist, int p1_log2, int k, int nkmax,
-                                                                size_t nthreads_total) {
+                                                                size_t nthreads_total, int canon) {
   __shared__ unsigned lh[SK_MAX_P1];  // records per bucket
   __shared__ unsigned lk[SK_MAX_P1];  // k-mers per bucket (bounds the bucket's survivors)
   const unsigned p1 = 1u << p1_log2;
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
     if (p0 >= seq_len) break;
     const u64 w0 = codes[t], w1 = codes[t + 1];
     const u64 badw = bad_window(bad, p0);
-    sk_for_each_record<W>(w0, w1, badw, k, nkmax, [&](int, int nk, unsigned mm) {
+    sk_for_each_record<W>(w0, w1, badw, k, nkmax, canon != 0, [&](int, int nk, unsigned mm) {
       const unsigned b = sk_bucket(mm, p1_log2);
       atomicAdd(&lh[b], 1u);
       atomicAdd(&lk[b], (unsigned)nk);
@@ -192,7 +203,7 @@ template <int W>
 __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                    const MkChunkInfo* __restrict__ info,
                                                                    u64* __restrict__ cursor, ulonglong2* __restrict__ part,
-                                                                   int p1_log2, int k, int nkmax, size_t ntiles) {
+                                                                   int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
   __shared__ unsigned lh[SK_MAX_P1];
   __shared__ u64 gbase[SK_MAX_P1];
   constexpr int NB = SK_MAX_P1 / SK_SCAT_THREADS;
@@ -214,8 +225,8 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
       if (p0 < seq_len) {
         ww0[st] = codes[t];
         ww1[st] = codes[t + 1];
-        runs[st] = sk_analyse<W>(ww0[st], ww1[st], bad_window(bad, p0), k);
-        sk_walk(runs[st], ww0[st], ww1[st], nkmax,
+        runs[st] = sk_analyse<W>(ww0[st], ww1[st], bad_window(bad, p0), k, canon != 0);
+        sk_walk(runs[st], ww0[st], ww1[st], nkmax, canon != 0,
                 [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
       }
     }
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
 #pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
       const u64 w0 = ww0[st], w1 = ww1[st];
-      sk_walk(runs[st], w0, w1, nkmax, [&](int jstart, int nk, unsigned mm) {
+      sk_walk(runs[st], w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
         part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk_make_record(w0, w1, jstart, nk, k);
       });
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
                                                              int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
-                                                             int dflags) {
+                                                             int dflags, int canon) {
   __shared__ u64 tkey[SKC_SLOTS];
   __shared__ unsigned tcnt[SKC_SLOTS];
   // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
               unsigned hh[SKC_B];
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u) {
-                kk[u] = (base + u < nk) ? (x >> kshift) : MK_EMPTY;
+                kk[u] = (base + u < nk) ? mk_canon2(x >> kshift, k, canon != 0) : MK_EMPTY;
                 if (base + u < nk && kk[u] == MK_EMPTY) side_pass += side_done ? 0 : 1;
                 x = (x << 2) | (y >> 62);
                 y <<= 2;
@@ -544,11 +555,11 @@ static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, u64* his
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end
   hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK_HIST_THREADS), 0, c->stream,
-                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads);
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical);
   mk_launch_part_scan(c, hist, start, cursor, p1_log2);
   hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (ulonglong2*)c->part.p, p1_log2,
-                     c->k, nkmax, stiles);
+                     c->k, nkmax, stiles, c->canonical);
 }
 
 #ifdef MK_STAMP
@@ -610,7 +621,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     hipLaunchKernelGGL(mk_sk_count_k, dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p,
                        (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                        (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf,
-                       getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0);
+                       getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0, c->canonical);
   }
   mk_prof_end(c);
 #ifdef MK_STAMP

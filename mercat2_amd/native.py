@@ -22,7 +22,7 @@ ERR_NAMES = {-1: "MK_ERR_ARG", -2: "MK_ERR_HIP", -3: "MK_ERR_NOMEM", -4: "MK_ERR
 
 # every symbol include/mercat_hip.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
-    "mk_create", "mk_destroy", "mk_last_error", "mk_reset", "mk_chunk_begin", "mk_chunk_feed",
+    "mk_create", "mk_destroy", "mk_last_error", "mk_reset", "mk_set_canonical", "mk_chunk_begin", "mk_chunk_feed",
     "mk_chunk_feed_device", "mk_chunk_end", "mk_count_device", "mk_export_size", "mk_export",
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
     "mk_import_exotic", "mk_words_per_key", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         "mk_destroy": (None, [vp]),
         "mk_last_error": (C.c_char_p, [vp]),
         "mk_reset": (C.c_int, [vp]),
+        "mk_set_canonical": (C.c_int, [vp, C.c_int]),
         "mk_chunk_begin": (C.c_int, [vp]),
         "mk_chunk_feed": (C.c_int, [vp, u8p, C.c_size_t]),
         "mk_chunk_feed_device": (C.c_int, [vp, u8p, C.c_size_t]),
@@ -161,7 +162,7 @@ def synth_reads(genome_len: int, genome_seed: int, reads: int, read_len: int, re
 class Counter:
     """One GPU counting context for a fixed (alphabet, k): wraps mk_ctx."""
 
-    def __init__(self, k: int, alphabet: int = ALPHABET_NT2, device: int = 0):
+    def __init__(self, k: int, alphabet: int = ALPHABET_NT2, device: int = 0, canonical: bool = False):
         self._L = lib()
         self._h = C.c_void_p()
         self.k, self.alphabet, self.device = int(k), int(alphabet), int(device)
@@ -169,6 +170,8 @@ class Counter:
         if rc:
             msg = self._L.mk_last_error(None)
             raise MercatHipError(rc, msg.decode() if msg else "mk_create")
+        if canonical:
+            self.set_canonical(True)
 
     # -- plumbing
     def _check(self, rc: int):
@@ -195,6 +198,10 @@ class Counter:
             pass
 
     # -- counting
+    def set_canonical(self, on: bool):
+        """Opt-in extension (not reference behaviour): count min(kmer, reverse complement)."""
+        self._check(self._L.mk_set_canonical(self._h, 1 if on else 0))
+
     def reset(self):
         self._check(self._L.mk_reset(self._h))
 

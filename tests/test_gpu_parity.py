@@ -281,3 +281,41 @@ def test_cli_writes_reference_tsv(tmp_path, capsys):
     assert cli.main(["-i", str(src), "-k", "5", "-c", "100000", "-o", str(out2)]) == 0
     assert not (out2 / "tsv_protein" / "RW1_pro_counts.tsv").exists()
     assert "No significant k-mers found" in capsys.readouterr().out
+
+
+def _fold_filter(table, c):
+    return {key: n for key, n in cpu_ref.canonical_fold(table).items() if n >= c}
+
+
+@pytest.mark.parametrize("k", [3, 7, 12, 17, 21, 31, 32])
+def test_canonical_mode_is_the_folded_reference(k):
+    """Opt-in canonical counting (north_star / BASELINE config 3; NOT reference behaviour):
+    oracle = reference counts with min_count 0, every ACGT-only key folded onto
+    min(key, reverse complement), then the per-chunk filter."""
+    from oracle import c_oracle
+    synth = native.synth_reads(30_000, 41, 20_000, 150, 42).tobytes()
+    for data, c in [(read_input("edge_lengths.fa"), 1), (read_input("edge_reads.fna"), 2), (synth, 3)]:
+        with native.Counter(k, native.ALPHABET_NT2, canonical=True) as ctx:
+            ctx.count_chunk(data, c)
+            got = ctx.to_dict()
+        assert got == _fold_filter(c_oracle.count_dict(data, k, 0), c), (k, c, len(data))
+
+
+def test_canonical_mode_chunked_and_guards():
+    from oracle import c_oracle
+    k, c = 31, 2
+    data = native.synth_reads(30_000, 43, 40_000, 150, 44).tobytes()
+    offs = chunk_offsets(data, 2_000_000)
+    assert len(offs) > 3
+    with native.Counter(k, native.ALPHABET_NT2, canonical=True) as ctx:
+        for a, b in zip(offs[:-1], offs[1:]):
+            ctx.count_chunk(memoryview(data)[a:b], c)
+        got = ctx.to_dict()
+        with pytest.raises(native.MercatHipError):
+            ctx.set_canonical(False)  # rows counted in the other mode are in the table
+        ctx.reset()
+        ctx.set_canonical(False)
+    want = cpu_ref.merge_counts(_fold_filter(c_oracle.count_dict(data[a:b], k, 0), c) for a, b in zip(offs[:-1], offs[1:]))
+    assert got == want
+    with pytest.raises(native.MercatHipError):
+        native.Counter(3, native.ALPHABET_AA5, canonical=True)
