@@ -122,8 +122,6 @@ def main():
     out_cap = 2 * GENOME + 1024  # distinct forward-strand k-mers of both strands, upper bound
     out_keys = torch.empty(out_cap, dtype=torch.int64, device=dev)
     out_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev)
-    tmp_keys = torch.empty(out_cap, dtype=torch.int64, device=dev) if nctx > 1 else None
-    tmp_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev) if nctx > 1 else None
     base_ptr = text.data_ptr()
     chunks = list(zip(offs[:-1], offs[1:]))
 
@@ -139,9 +137,7 @@ def main():
         else:
             list(pool.map(count_share, range(nctx)))
             for c in ctxs[1:]:  # sum the other contexts' survivors into context 0, on the device
-                n = c.export_pairs_device(tmp_keys.data_ptr(), tmp_cnts.data_ptr(), out_cap)
-                if n:
-                    ctx.import_pairs_device(tmp_keys.data_ptr(), tmp_cnts.data_ptr(), n)
+                ctx.merge_from(c)
         if world > 1:
             merge_ranks(ctx, key_bits, device=dev)
         return ctx.export_pairs_device(out_keys.data_ptr(), out_cnts.data_ptr(), out_cap)

@@ -115,6 +115,10 @@ int mk_import_pairs_device(mk_ctx* ctx, const uint64_t* d_keys, const uint64_t* 
 int mk_export_exotic(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t cap, size_t* rows);
 int mk_import_exotic(mk_ctx* ctx, const uint8_t* kmers, const uint64_t* counts, size_t rows);
 int mk_words_per_key(const mk_ctx* ctx);
+/* Add every row of src's running table into dst's (both on the same GPU, same alphabet, k and
+ * canonical mode); src is left unchanged.  Lets a host deal the chunks of one sample to several
+ * contexts (= HIP streams) that count concurrently and sum them at the end, on the device. */
+int mk_merge_from(mk_ctx* dst, mk_ctx* src);
 
 /* ---- statistics / profiling ----------------------------------------------------------- */
 int mk_set_profiling(mk_ctx* ctx, int on);

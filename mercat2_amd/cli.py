@@ -32,6 +32,9 @@ def parseargs(argv=None):
     p.add_argument("-o", type=str, default="mercat_results", required=False, help="Output folder")
     p.add_argument("-replace", action="store_true", help="Replace existing output directory [False]")
     p.add_argument("-gpu", type=int, default=0, help="HIP device index [0]")
+    p.add_argument("-streams", type=int, default=2, help="engine contexts counting chunks concurrently [2]")
+    p.add_argument("-canonical", action="store_true",
+                   help="EXTENSION (not MerCat2 behaviour): count min(kmer, reverse complement) for nucleotide input")
     p.add_argument("--version", "-v", action="version", version=f"mercat2_amd {__version__}")
     args = p.parse_args(argv)
     if not args.i and not args.f:
@@ -85,7 +88,8 @@ def main(argv=None) -> int:
         tsv_dir.mkdir(parents=True, exist_ok=True)
         start = timeit.default_timer()
         for base, f in samples[kind].items():
-            run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu)
+            run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
+                       streams=args.streams, canonical=args.canonical)
         print(f"Time to count {args.k}-mers: {round(timeit.default_timer() - start, 2)} seconds")
     return 0
 

@@ -701,6 +701,41 @@ extern "C" int mk_import_exotic(mk_ctx* c, const uint8_t* kmers, const uint64_t*
   return MK_OK;
 }
 
+extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
+  if (!dst || !src || dst == src) return MK_ERR_ARG;
+  mk_ctx* c = dst;
+  if (dst->device != src->device || dst->alphabet != src->alphabet || dst->k != src->k || dst->canonical != src->canonical) {
+    c->err = "mk_merge_from: contexts differ in device, alphabet, k or canonical mode";
+    return MK_ERR_ARG;
+  }
+  if (dst->in_chunk || src->in_chunk) { c->err = "mk_merge_from: a chunk is open"; return MK_ERR_STATE; }
+  MK_HIP(hipSetDevice(dst->device));
+  int rc;
+  if (src->mode != MK_MODE_BYREF) {
+    size_t cap = 0;
+    if ((rc = mk_export_size(src, &cap)) != MK_OK) { dst->err = src->err; return rc; }
+    cap += 1;
+    if ((rc = mk_buf_reserve(dst, dst->surv_keys, cap * 8 + 64)) != MK_OK) return rc;
+    if ((rc = mk_buf_reserve(dst, dst->surv_cnts, cap * 8 + 64)) != MK_OK) return rc;
+    size_t rows = 0;
+    if ((rc = mk_export_pairs_device(src, (uint64_t*)dst->surv_keys.p, (uint64_t*)dst->surv_cnts.p, cap, &rows)) != MK_OK) {
+      dst->err = src->err;
+      return rc;
+    }
+    if (rows && (rc = mk_import_pairs_device(dst, (const uint64_t*)dst->surv_keys.p, (const uint64_t*)dst->surv_cnts.p, rows)) != MK_OK)
+      return rc;
+  }
+  if (src->run_ref_rows) {
+    size_t n = 0;
+    if ((rc = mk_export_exotic(src, nullptr, nullptr, 0, &n)) != MK_OK) { dst->err = src->err; return rc; }
+    std::vector<uint8_t> km(n * (size_t)src->k + 1);
+    std::vector<uint64_t> cn(n + 1);
+    if ((rc = mk_export_exotic(src, km.data(), cn.data(), n, &n)) != MK_OK) { dst->err = src->err; return rc; }
+    if ((rc = mk_import_exotic(dst, km.data(), cn.data(), n)) != MK_OK) return rc;
+  }
+  return MK_OK;
+}
+
 // ----------------------------------------------------------------------------------- stats
 extern "C" int mk_set_profiling(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;

@@ -57,15 +57,36 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
-               *, device: int = 0) -> Tuple[str, Optional[os.PathLike]]:
+               *, device: int = 0, streams: int = 2, canonical: bool = False) -> Tuple[str, Optional[os.PathLike]]:
     """chunk_files + run_mercat2 in one step with no chunk files: the file is read (inflated)
     once, the reference's cut points are computed over the bytes, and each byte range is
-    counted as one chunk.  Same TSV as the two-step path."""
+    counted as one chunk (filtered on its own).  Same TSV as the two-step path.
+
+    ``streams`` contexts (HIP streams) count different chunks concurrently -- the host-to-device
+    copy and parse of one chunk overlap the LDS-bound counting of another -- and are summed on
+    the device at the end (mk_merge_from).  ``canonical`` is the opt-in extension of
+    mk_set_canonical (not reference behaviour)."""
+    from concurrent.futures import ThreadPoolExecutor
     data = read_fasta_bytes(file)
     chunked = chunk_mib > 0 and os.stat(file).st_size >= chunk_mib * 1024 * 1024
     offs = chunk_offsets(data, chunk_mib * 1024 * 1024) if chunked else [0, len(data)]
+    chunks = list(zip(offs[:-1], offs[1:]))
     view = memoryview(data)
-    with native.Counter(kmer, guess_alphabet(file, data), device) as ctx:
-        for a, b in zip(offs[:-1], offs[1:]):
-            ctx.count_chunk(view[a:b], min_count)
-        return _finish(ctx, basename, out_file)
+    alphabet = guess_alphabet(file, data)
+    n = max(1, min(int(streams), len(chunks)))
+    ctxs = [native.Counter(kmer, alphabet, device, canonical=canonical and alphabet == native.ALPHABET_NT2) for _ in range(n)]
+    try:
+        def share(i):
+            for a, b in chunks[i::n]:
+                ctxs[i].count_chunk(view[a:b], min_count)
+        if n == 1:
+            share(0)
+        else:
+            with ThreadPoolExecutor(n) as pool:  # ctypes releases the GIL inside the ABI calls
+                list(pool.map(share, range(n)))
+            for other in ctxs[1:]:
+                ctxs[0].merge_from(other)
+        return _finish(ctxs[0], basename, out_file)
+    finally:
+        for c in ctxs:
+            c.close()

@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "mk_create", "mk_destroy", "mk_last_error", "mk_reset", "mk_set_canonical", "mk_chunk_begin", "mk_chunk_feed",
     "mk_chunk_feed_device", "mk_chunk_end", "mk_count_device", "mk_export_size", "mk_export",
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
-    "mk_import_exotic", "mk_words_per_key", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
+    "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version",
 ]
 
@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
         "mk_export_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t, szp]),
         "mk_import_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t]),
         "mk_words_per_key": (C.c_int, [vp]),
+        "mk_merge_from": (C.c_int, [vp, vp]),
         "mk_set_profiling": (C.c_int, [vp, C.c_int]),
         "mk_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "mk_reset_stats": (C.c_int, [vp]),
@@ -257,6 +258,10 @@ class Counter:
 
     def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
         self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
+
+    def merge_from(self, other: "Counter"):
+        """Add every row of ``other`` (same GPU, alphabet, k) into this context, on the device."""
+        self._check(self._L.mk_merge_from(self._h, other._h))
 
     def export_exotic(self) -> Tuple[np.ndarray, np.ndarray]:
         n = C.c_size_t(0)

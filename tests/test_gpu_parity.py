@@ -319,3 +319,20 @@ def test_canonical_mode_chunked_and_guards():
     assert got == want
     with pytest.raises(native.MercatHipError):
         native.Counter(3, native.ALPHABET_AA5, canonical=True)
+
+
+def test_run_sample_streams_and_merge_from(tmp_path):
+    """harness.run_sample with 1, 2 and 3 contexts writes the same TSV as the reference
+    composition (chunk -> count with its own filter -> sum), incl. by-reference rows."""
+    from mercat2_amd import harness
+    data = native.synth_reads(40_000, 51, 30_000, 150, 52).tobytes() + read_input("edge_lengths.fa")
+    src = tmp_path / "s.fna"
+    src.write_bytes(data)
+    k, c = 21, 2
+    offs = chunk_offsets(data, 1024 * 1024)
+    want = cpu_ref.tsv_text("s", cpu_ref.merge_counts(cpu_ref.count_text(data[a:b], k, c) for a, b in zip(offs[:-1], offs[1:])))
+    assert len(offs) > 4
+    for streams in (1, 2, 3):
+        out = tmp_path / ("s_%d.tsv" % streams)
+        assert harness.run_sample("s", src, out, k, c, chunk_mib=1, streams=streams) == ("s", out)
+        assert out.read_text() == want, streams
