@@ -92,11 +92,16 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    backend = os.environ.get("MK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a 1-GPU box
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mercat2_amd import native
     from mercat2_amd.chunker import chunk_offsets
@@ -168,8 +173,9 @@ def main():
             if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct"):
                 st[key] += val
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    r = torch.tensor([rows], dtype=torch.int64, device=dev)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    r = torch.tensor([rows], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
