@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 
 from . import native
 from .chunker import Chunker, chunk_offsets
-from .kmers import find_kmers, guess_alphabet, read_fasta_bytes
+from .kmers import find_kmers, guess_alphabet, map_fasta, read_fasta_bytes
 
 
 def chunk_files(name: str, filename: str, chunk_size: int, outpath: str) -> Tuple[str, List[str]]:
@@ -67,7 +67,7 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
     the device at the end (mk_merge_from).  ``canonical`` is the opt-in extension of
     mk_set_canonical (not reference behaviour)."""
     from concurrent.futures import ThreadPoolExecutor
-    data = read_fasta_bytes(file)
+    data = map_fasta(file)  # plain files: memory-mapped, no host copy
     chunked = chunk_mib > 0 and os.stat(file).st_size >= chunk_mib * 1024 * 1024
     offs = chunk_offsets(data, chunk_mib * 1024 * 1024) if chunked else [0, len(data)]
     chunks = list(zip(offs[:-1], offs[1:]))

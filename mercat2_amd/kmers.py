@@ -25,16 +25,31 @@ def read_fasta_bytes(file: Union[str, Path]) -> bytes:
     return p.read_bytes()
 
 
+def map_fasta(file: Union[str, Path]):
+    """Buffer over the (decompressed) bytes of a FASTA without an extra copy where possible:
+    plain files are memory-mapped (the engine copies straight from the page cache to the GPU),
+    '.gz' files are inflated into memory.  Returns an object supporting the buffer protocol."""
+    import mmap
+    p = Path(file)
+    if p.suffix == ".gz":
+        return read_fasta_bytes(p)
+    size = p.stat().st_size
+    if size == 0:
+        return b""
+    with open(p, "rb") as fh:
+        return mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+
+
 def guess_alphabet(file: Union[str, Path], data: Optional[bytes] = None) -> int:
     """Pick the packed fast path. Correctness never depends on it: characters outside the
     chosen alphabet are still counted exactly (by the by-reference kernel)."""
     name = str(file).lower()
     if name.endswith(PROTEIN_SUFFIXES):
         return native.ALPHABET_AA5
-    if data:
+    if data is not None and len(data):
         # chunk files written by the Chunker lose the '.gz' but keep '.faa'; anything else:
         # sniff the first sequence lines
-        seq = b"".join(l for l in data[:4096].splitlines() if l and not l.startswith(b">"))
+        seq = b"".join(l for l in bytes(data[:4096]).splitlines() if l and not l.startswith(b">"))
         if seq:
             acgt = sum(seq.count(c) for c in (b"A", b"C", b"G", b"T", b"N", b"a", b"c", b"g", b"t", b"n"))
             if acgt < 0.9 * len(seq):

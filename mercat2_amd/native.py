@@ -113,8 +113,8 @@ def _buf_ptr(data) -> Tuple[int, int, object]:
     mv = memoryview(data)
     if mv.nbytes == 0:
         return 0, 0, None
-    a = np.frombuffer(mv, dtype=np.uint8)
-    return a.ctypes.data, a.nbytes, a
+    a = np.frombuffer(mv, dtype=np.uint8)  # works for read-only buffers (bytes, mmap) too
+    return a.__array_interface__["data"][0], a.nbytes, a
 
 
 def _big_u8(n: int) -> np.ndarray:
