@@ -194,7 +194,7 @@ def main():
         stage_bytes = packed_windows * 16 + st["symbols"] * 0.25
         stage_achieved = stage_bytes / launches / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
         kernel_name = {"hash64": "mk_sk_count_k" if 18 <= k <= 32 else "mk_part_count_k", "dense": "mk_count_dense_k",
-                       "byref": "mk_count_byref_k"}.get(st["mode_name"], "?")
+                       "byref": "mk_count_byref_k", "ref128": "mk_count_ref128_k"}.get(st["mode_name"], "?")
         if os.environ.get("MK_NO_PARTITION"):
             kernel_name = "mk_count_hash64_k"
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in

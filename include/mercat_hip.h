@@ -53,7 +53,8 @@ typedef struct mk_stats_t {
   uint64_t survivors;      /* chunk-table entries that passed their chunk's min_count       */
   uint64_t rows;           /* distinct k-mers now in the running (merged) table             */
   uint64_t table_slots;    /* slots (or dense bins) of the chunk table of the last chunk    */
-  int32_t mode;            /* 0 dense-LDS, 1 hash64, 2 hash128, 3 by-reference only          */
+  int32_t mode;            /* 0 dense-LDS, 1 hash64 (packed keys), 2 ref128 (33..64-mers: by reference,
+                              packed 128-bit hashing/compare), 3 by-reference on bytes only      */
   int32_t profiled;        /* 1 when per-kernel HIP-event timing is on (mk_set_profiling)   */
   /* HIP-event time per kernel family, milliseconds, and launches (only when profiled) */
   double ms_parse, ms_pack, ms_count, ms_exotic, ms_filter, ms_export;

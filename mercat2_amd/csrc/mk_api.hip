@@ -137,6 +137,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->syms_per_word = alphabet == MK_ALPHABET_NT2 ? 32 : 12;
   const long kb = (long)k * c->bits;
   c->mode = (c->bits == 0) ? MK_MODE_BYREF : (kb <= 15 ? MK_MODE_DENSE : (kb <= 64 ? MK_MODE_HASH64 : MK_MODE_BYREF));
+  if (alphabet == MK_ALPHABET_NT2 && k >= 33 && k <= 64) c->mode = MK_MODE_HASH128;  // packed by-reference
   c->st.mode = c->mode;
   c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
@@ -206,6 +207,7 @@ extern "C" int mk_reset(mk_ctx* c) {
 extern "C" int mk_set_canonical(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;
   if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_canonical: only the nucleotide alphabet has a reverse complement"; return MK_ERR_ARG; }
+  if (on && c->mode != MK_MODE_DENSE && c->mode != MK_MODE_HASH64) { c->err = "mk_set_canonical: canonical counting is implemented for k <= 32"; return MK_ERR_ARG; }
   if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run_side || c->st.chunks) {
     if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run_side || c->in_chunk)) {
       c->err = "mk_set_canonical: the running table already holds rows counted in the other mode (mk_reset first)";
@@ -323,7 +325,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_buf_reserve(c, c->ctab, c->ctab_slots * sizeof(MkSlot))) != MK_OK) return rc;
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
   }
-  if (c->mode == MK_MODE_BYREF) {
+  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) {
     c->rtab_chunk_slots = pow2_at_least(2 * seq_len);
   } else if (bad_symbols) {
     const u64 bound = std::min<u64>((u64)seq_len, bad_symbols * (u64)c->k);
@@ -333,7 +335,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_buf_reserve(c, c->rtab_chunk, c->rtab_chunk_slots * sizeof(MkSlot))) != MK_OK) return rc;
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots)) != MK_OK) return rc;
   }
-  c->st.table_slots = c->mode == MK_MODE_BYREF ? c->rtab_chunk_slots : c->ctab_slots;
+  c->st.table_slots = (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) ? c->rtab_chunk_slots : c->ctab_slots;
 
   // count
   if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
@@ -342,8 +344,11 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
   }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
+  else if (c->mode == MK_MODE_HASH128) rc = mk_launch_count_ref128(c, seq_len);
   if (rc) return rc;
-  if (c->rtab_chunk_slots && (rc = mk_launch_count_byref(c, seq_len, packed)) != MK_OK) return rc;
+  // by reference, byte-wise: every window (raw mode) or only those holding a symbol outside the alphabet
+  if (c->rtab_chunk_slots && (c->mode != MK_MODE_HASH128 || bad_symbols) &&
+      (rc = mk_launch_count_byref(c, seq_len, packed)) != MK_OK) return rc;
 
   // filter (per chunk!) + merge
   if ((rc = mk_launch_count_survivors(c, min_count)) != MK_OK) return rc;
@@ -637,7 +642,7 @@ extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, s
 // ------------------------------------------------------------------- multi-GPU plumbing
 extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;
-  if (c->mode == MK_MODE_BYREF) { *rows = 0; return MK_OK; }
+  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) { *rows = 0; return MK_OK; }  // rows travel as text (mk_export_exotic)
   MK_HIP(hipSetDevice(c->device));
   ExportView v;
   return gather_packed(c, v, (u64*)d_keys, (u64*)d_counts, cap, rows, false);
@@ -646,7 +651,7 @@ extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_c
 extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
   if (!c) return MK_ERR_ARG;
   if (!rows) return MK_OK;
-  if (c->mode == MK_MODE_BYREF) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
+  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(c->device));
   int rc;
   MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
@@ -711,7 +716,7 @@ extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
   if (dst->in_chunk || src->in_chunk) { c->err = "mk_merge_from: a chunk is open"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(dst->device));
   int rc;
-  if (src->mode != MK_MODE_BYREF) {
+  if (src->mode == MK_MODE_DENSE || src->mode == MK_MODE_HASH64) {
     size_t cap = 0;
     if ((rc = mk_export_size(src, &cap)) != MK_OK) { dst->err = src->err; return rc; }
     cap += 1;

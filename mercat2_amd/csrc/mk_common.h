@@ -166,6 +166,8 @@ int mk_launch_pack(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_dense(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_hash64(mk_ctx* c, size_t seq_cap);
 int mk_launch_count_byref(mk_ctx* c, size_t seq_cap, bool exotic_only);
+// nt 33..64-mers without bad symbols: by reference with packed hashing/compare (mode MK_MODE_HASH128)
+int mk_launch_count_ref128(mk_ctx* c, size_t seq_len);
 // partitioned hash64 path: windows -> hash buckets -> per-bucket LDS tables -> survivors (count >= min_count)
 int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip

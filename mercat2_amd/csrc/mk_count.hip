@@ -211,6 +211,110 @@ __global__ __launch_bounds__(256) void mk_count_byref_k(const uint8_t* __restric
   add_windows(info, mine, true);
 }
 
+// ----------------------------------------------------------------- packed by-reference
+// 33 <= k <= 64 nucleotide windows without a bad symbol: the slot still stores the POSITION of
+// the first occurrence (no 128-bit compare-and-swap exists), but hashing and equality run on the
+// 2-bit packed stream: a window is its left-aligned 128-bit key, fetched from 3 packed words.
+struct Key128 {
+  u64 hi, lo;
+};
+
+// Left-aligned 2k-bit key of the window starting at base `pos` (k <= 64), low bits zeroed.
+__device__ __forceinline__ Key128 key128_at(const u64* __restrict__ codes, u64 pos, int k) {
+  const u64 w = pos >> 5;
+  const int sh = (int)(pos & 31) * 2;
+  const u64 a = codes[w], b = codes[w + 1], c = codes[w + 2];
+  Key128 r;
+  r.hi = sh ? ((a << sh) | (b >> (64 - sh))) : a;
+  r.lo = sh ? ((b << sh) | (c >> (64 - sh))) : b;
+  if (k <= 32) { r.hi &= (k == 32) ? ~0ull : (~0ull << (64 - 2 * k)); r.lo = 0; }
+  else if (k < 64) r.lo &= ~0ull << (128 - 2 * k);
+  return r;
+}
+
+__device__ __forceinline__ void insert_ref128(MkSlot* __restrict__ table, u64 mask, const u64* __restrict__ codes,
+                                              u64 pos, Key128 key, int k) {
+  const u64 h = mk_mix64(key.hi ^ mk_mix64(key.lo + 0x9E3779B97F4A7C15ull));
+  const u64 tag = (h >> 41) << REF_POS_BITS;
+  const u64 mine = tag | pos;
+  u64 slot = h & mask;
+  for (;;) {
+    u64 cur = table[slot].key;
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&table[slot].key, MK_EMPTY, mine);
+      if (cur == MK_EMPTY) {
+        atomicAdd(&table[slot].cnt, 1ull);
+        return;
+      }
+    }
+    if ((cur & ~REF_POS_MASK) == tag) {
+      const Key128 other = key128_at(codes, cur & REF_POS_MASK, k);
+      if (other.hi == key.hi && other.lo == key.lo) {
+        atomicAdd(&table[slot].cnt, 1ull);
+        return;
+      }
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+// One thread per 32 window starts; 4 packed words cover 32 + 63 bases.
+__global__ __launch_bounds__(256) void mk_count_ref128_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                         MkChunkInfo* __restrict__ info, MkSlot* __restrict__ table,
+                                                         u64 mask, int k) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t p0 = t * 32;
+  unsigned mine = 0;
+  if (p0 < info->seq_len) {
+    const u64 w0 = codes[t], w1 = codes[t + 1], w2 = codes[t + 2], w3 = codes[t + 3];
+    // 128 bad bits for bases p0 .. p0+127 (p0 is a multiple of 32)
+    const size_t bi = p0 >> 6;
+    u64 b_lo, b_hi;
+    if (p0 & 63) {
+      const u64 x0 = bad[bi], x1 = bad[bi + 1], x2 = bad[bi + 2];
+      b_lo = (x0 >> 32) | (x1 << 32);
+      b_hi = (x1 >> 32) | (x2 << 32);
+    } else {
+      b_lo = bad[bi];
+      b_hi = bad[bi + 1];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      // window j is clean iff bad bits j .. j+k-1 are zero
+      const u64 lo_part = b_lo >> j;                       // bits j..63 of b_lo -> 64-j bits
+      const u64 hi_part = j ? (b_hi << (64 - j)) : 0ull;   // next bits
+      const u64 win_lo = lo_part | hi_part;                // bad bits j .. j+63
+      const u64 win_hi = b_hi >> j;                        // bad bits j+64 .. (only needed for k = 64 & j > 0: none)
+      const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+      (void)win_hi;
+      if ((win_lo & kmask) == 0) {
+        const int sh = 2 * j;
+        Key128 key;
+        key.hi = sh ? ((w0 << sh) | (w1 >> (64 - sh))) : w0;
+        key.lo = sh ? ((w1 << sh) | (w2 >> (64 - sh))) : w1;
+        if (k < 64) key.lo &= ~0ull << (128 - 2 * k);
+        (void)w3;
+        insert_ref128(table, mask, codes, (u64)(p0 + j), key, k);
+        ++mine;
+      }
+    }
+  }
+  add_windows(info, mine, true);
+}
+
+int mk_launch_count_ref128(mk_ctx* c, size_t seq_len) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const size_t threads = (seq_len + 31) / 32;
+  mk_prof_begin(c, MK_K_COUNT);
+  hipLaunchKernelGGL(mk_count_ref128_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->rtab_chunk.p,
+                     (u64)(c->rtab_chunk_slots - 1), c->k);
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 // ------------------------------------------------------------------------------ launchers
 static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 

@@ -75,7 +75,7 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None) -> int:
         return ctx.rows()
     dev = device if device is not None else torch.device("cuda", ctx.device)
     st = ctx.stats()
-    packed = st["mode_name"] != "byref"
+    packed = st["mode_name"] in ("dense", "hash64")  # the other modes keep their rows as text
     if packed:
         cap = ctx.rows() + 1
         keys = torch.empty(cap, dtype=torch.int64, device=dev)

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 ALPHABET_NT2, ALPHABET_AA5, ALPHABET_RAW = 0, 1, 2
-MODE_NAMES = {0: "dense", 1: "hash64", 2: "hash128", 3: "byref"}
+MODE_NAMES = {0: "dense", 1: "hash64", 2: "ref128", 3: "byref"}
 
 MK_OK = 0
 ERR_NAMES = {-1: "MK_ERR_ARG", -2: "MK_ERR_HIP", -3: "MK_ERR_NOMEM", -4: "MK_ERR_STATE",

@@ -336,3 +336,19 @@ def test_run_sample_streams_and_merge_from(tmp_path):
         out = tmp_path / ("s_%d.tsv" % streams)
         assert harness.run_sample("s", src, out, k, c, chunk_mib=1, streams=streams) == ("s", out)
         assert out.read_text() == want, streams
+
+
+@pytest.mark.parametrize("k", [33, 48, 63, 64])
+def test_large_k_packed_by_reference_vs_c_oracle(k):
+    """33..64-mers (BASELINE config 5 uses k=63): packed by-reference kernel for the clean windows,
+    byte-wise by-reference kernel for windows with N / lower case, one shared table."""
+    from oracle import c_oracle
+    reads = native.synth_reads(200_000, 61, 100_000, 150, 62, 3000).tobytes()
+    odd = read_input("edge_lengths.fa") + b">mixed\n" + b"ACGTNNNNacgtACGTTGCA" * 40 + b"\n"
+    data = reads + odd
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, 2)
+        kmers, counts = ctx.export()
+        assert ctx.stats()["mode_name"] == "ref128"
+    okm, ocn = c_oracle.count(data, k, 2)
+    assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn)
