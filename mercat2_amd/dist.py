@@ -89,9 +89,15 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None) -> int:
         if rk.numel():
             torch.cuda.synchronize(dev) if dev.type == "cuda" else None
             ctx.import_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (ex_k, ex_c), group=group)
-    if rank == 0:
-        for k_arr, c_arr in gathered:
-            ctx.import_exotic(k_arr, c_arr)
+    # by-reference rows (text keys) are rare: one small all_reduce tells whether any rank has some,
+    # and only then are they gathered (as objects) and summed on rank 0
+    red_dev = dev if dist.get_backend(group) != "gloo" else torch.device("cpu")
+    any_ref = torch.tensor([int(ex_c.size)], dtype=torch.int64, device=red_dev)
+    dist.all_reduce(any_ref, group=group)
+    if int(any_ref.item()):
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (ex_k, ex_c), group=group)
+        if rank == 0:
+            for k_arr, c_arr in gathered:
+                ctx.import_exotic(k_arr, c_arr)
     return ctx.rows()

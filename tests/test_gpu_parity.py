@@ -352,3 +352,24 @@ def test_large_k_packed_by_reference_vs_c_oracle(k):
         assert ctx.stats()["mode_name"] == "ref128"
     okm, ocn = c_oracle.count(data, k, 2)
     assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn)
+
+
+def test_low_complexity_and_repeats():
+    """Skewed input: long homopolymer and dinucleotide runs and a tandem repeat put most windows
+    into a few minimizer buckets (and a handful of keys); counts must stay exact."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(11)
+    unit = "".join("ACGT"[i] for i in rng.integers(0, 4, 500))
+    recs = []
+    for i in range(300):
+        recs.append(">a%d\n%s\n" % (i, "A" * 2000))
+        recs.append(">at%d\n%s\n" % (i, "AT" * 1000))
+        recs.append(">rep%d\n%s\n" % (i, unit * 5))
+        recs.append(">t%d\n%s\n" % (i, "T" * 700 + unit[:300]))
+    data = "".join(recs).encode()
+    for k in (12, 21, 31, 32, 40):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, 10)
+            kmers, counts = ctx.export()
+        okm, ocn = c_oracle.count(data, k, 10)
+        assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
