@@ -142,6 +142,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
   c->use_superkmer = getenv("MK_NO_SUPERKMER") ? 0 : 1;
+  c->use_superkmer2 = getenv("MK_NO_SUPERKMER2") ? 0 : 1;
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {
     g_err = msg;
@@ -175,7 +176,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
-                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts};
+                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -325,7 +326,8 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_buf_reserve(c, c->ctab, c->ctab_slots * sizeof(MkSlot))) != MK_OK) return rc;
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
   }
-  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) {
+  const bool sk2 = c->mode == MK_MODE_HASH128 && c->use_superkmer2;  // partitioned path: no global chunk table
+  if (c->mode == MK_MODE_BYREF || (c->mode == MK_MODE_HASH128 && !sk2)) {
     c->rtab_chunk_slots = pow2_at_least(2 * seq_len);
   } else if (bad_symbols) {
     const u64 bound = std::min<u64>((u64)seq_len, bad_symbols * (u64)c->k);
@@ -344,7 +346,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
   }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
-  else if (c->mode == MK_MODE_HASH128) rc = mk_launch_count_ref128(c, seq_len);
+  else if (c->mode == MK_MODE_HASH128) rc = sk2 ? mk_launch_count_superkmer2(c, seq_len, min_count) : mk_launch_count_ref128(c, seq_len);
   if (rc) return rc;
   // by reference, byte-wise: every window (raw mode) or only those holding a symbol outside the alphabet
   if (c->rtab_chunk_slots && (c->mode != MK_MODE_HASH128 || bad_symbols) &&
@@ -361,6 +363,15 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = grow_run64(c, c->run_rows + (size_t)c->h_info->survivors)) != MK_OK) return rc;
   if (c->h_info->survivors_ref)
     if ((rc = grow_run_ref(c, c->run_ref_rows + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
+  if (sk2 && c->surv_regions == 2 && seq_len) {
+    const size_t p1 = (size_t)1 << c->p1_log2;
+    const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
+    mk_prof_begin(c, MK_K_FILTER);
+    rc = mk_launch_import_ref128_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_keys2.p,
+                                         (const uint64_t*)c->surv_cnts.p, meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+    mk_prof_end(c);
+    if (rc) return rc;
+  }
   if (partitioned && c->h_info->survivors) {
     mk_prof_begin(c, MK_K_FILTER);
     if (c->surv_regions) {
@@ -380,7 +391,9 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
   if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
-  if (partitioned && c->h_info->records) c->nk_hint = (double)c->h_info->windows / (double)c->h_info->records;
+  if (sk2 && c->h_info->distinct) c->dup_hint = (double)c->h_info->exotic / (double)c->h_info->distinct;
+  if ((partitioned || sk2) && c->h_info->records)
+    c->nk_hint = (double)(c->h_info->windows + c->h_info->exotic) / (double)c->h_info->records;
 
   if (getenv("MK_VERBOSE"))
     fprintf(stderr, "[mk] chunk: raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu new_rows=%llu p1=2^%d dup=%.2f nk=%.2f\n", n, seq_len,

@@ -128,6 +128,8 @@ struct mk_ctx {
   MkDevBuf part;        // u64 keys, bucket after bucket
   MkDevBuf part_meta;   // u64 hist[P1] | start[P1+1] | cursor[P1]
   MkDevBuf surv_keys, surv_cnts;  // (key,count) survivors of the chunk
+  MkDevBuf surv_keys2;            // second key word of the survivors (33..64-mers)
+  int use_superkmer2 = 1;
   int p1_log2 = 10;
   double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
   int use_partition = 1;
@@ -172,6 +174,10 @@ int mk_launch_count_ref128(mk_ctx* c, size_t seq_len);
 int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip
 int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count);
+// nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
+int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count);
+int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,
+                                    const uint64_t* kstart, const uint64_t* nsurv, size_t p1);
 // tables
 int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
 int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);

@@ -72,6 +72,16 @@ __device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
 
 // Result of analysing a thread's 32 windows: which are valid, where runs start, and the 6-bit
 // minimizer position of every window (packed 10 per word).
+// Windows j = 0..31 whose k bases are all clean, from the 64 bad bits that start at the thread's
+// first base (k <= 33: j + k - 1 <= 63).
+__device__ __forceinline__ unsigned sk_valid32(u64 badw, int k) {
+  const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+  unsigned v = 0;
+#pragma unroll
+  for (int j = 0; j < SK_R; ++j) v |= (((badw >> j) & kmask) == 0) ? (1u << j) : 0u;
+  return v;
+}
+
 struct SkRuns {
   unsigned valid, starts;
   u64 pos[4];
@@ -80,7 +90,7 @@ struct SkRuns {
 // W = k - SK_M + 1 minimizer candidates per window (compile time: the sliding minimum is a
 // doubling network with static indices).
 template <int W>
-__device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k, bool canon) {
+__device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, unsigned valid, bool canon) {
   constexpr int NQ = SK_R + W - 1;  // candidate positions 0 .. NQ-1
   unsigned ord[NQ];
   {
@@ -101,19 +111,17 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, u64 badw, int k, bo
 #pragma unroll
     for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
   }
-  // static, branch-free: valid windows, minimizer positions, run starts (first valid window,
-  // minimizer moved, or previous window invalid)
-  const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+  // static, branch-free: minimizer positions and run starts (first valid window, minimizer
+  // moved, or previous window invalid)
   SkRuns r;
-  r.valid = 0;
+  r.valid = valid;
   r.starts = 0;
   r.pos[0] = r.pos[1] = r.pos[2] = r.pos[3] = 0;
   unsigned prev_pos = 64;  // impossible position: window 0 always starts a run
 #pragma unroll
   for (int j = 0; j < SK_R; ++j) {
-    const bool ok = ((badw >> j) & kmask) == 0;
+    const bool ok = (valid >> j) & 1u;
     const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
-    r.valid |= ok ? (1u << j) : 0u;
     r.starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
     prev_pos = ok ? best : 64u;
     r.pos[j / 10] |= (u64)best << (6 * (j % 10));
@@ -146,7 +154,7 @@ __device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkm
 
 template <int W, class F>
 __device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int k, int nkmax, bool canon, F&& emit) {
-  const SkRuns r = sk_analyse<W>(w0, w1, badw, k, canon);
+  const SkRuns r = sk_analyse<W>(w0, w1, sk_valid32(badw, k), canon);
   sk_walk(r, w0, w1, nkmax, canon, emit);
 }
 
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
       if (p0 < seq_len) {
         ww0[st] = codes[t];
         ww1[st] = codes[t + 1];
-        runs[st] = sk_analyse<W>(ww0[st], ww1[st], bad_window(bad, p0), k, canon != 0);
+        runs[st] = sk_analyse<W>(ww0[st], ww1[st], sk_valid32(bad_window(bad, p0), k), canon != 0);
         sk_walk(runs[st], ww0[st], ww1[st], nkmax, canon != 0,
                 [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
       }

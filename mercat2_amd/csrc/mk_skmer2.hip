@@ -1,0 +1,459 @@
+// mk_skmer2.hip -- super-k-mer partitioned counting for nucleotide 33 <= k <= 64 (two-word keys).
+//
+// Same scheme as mk_skmer.hip (which see) with these differences:
+//   * a window's bucket comes from the minimizer of its FIRST 32 bases (22 candidate 11-mers):
+//     still a function of the window's content only, and it lets the analysis reuse the k = 32
+//     instantiation; runs are cut into records of <= 8 windows;
+//   * a record is 32 bytes: up to 8 + 63 = 71 bases (142 bits) in three words + the run length;
+//   * the LDS table holds 128-bit keys {hi, lo} + a 32-bit count. There is no 128-bit
+//     compare-and-swap, so the COUNT word is the slot's state: 0 = free, LOCK = being written,
+//     otherwise the count. A lane claims a free slot by CAS(count, 0 -> LOCK), writes hi/lo and
+//     publishes with one atomic add (LOCK -> 1); lanes that meet LOCK look again on their next
+//     loop iteration (the owner finishes within the iteration in which it won, so lanes of the
+//     same wave cannot deadlock);
+//   * survivors leave the kernel as {hi, lo, count} in per-bucket regions and are added to the
+//     by-reference running table (text keys, mk_table.hip) by mk_import_ref128_regions_k -- the
+//     running table, the export and the multi-GPU merge are the ones the other large-k paths use.
+// Reference semantics: lib/mercat2_kmers.py:56-60 (every window +1), :73-76 (count >= min_count
+// per chunk).
+#include "mk_common.h"
+#include "mk_device.h"
+#include <cstdlib>
+
+#define SK2_R 32
+#define SK2_HIST_THREADS 256
+#define SK2_SCAT_THREADS 1024
+#define SK2_MAX_P1 8192
+#define SK2_NKMAX 8
+#define SK2C_SLOTS 4096
+#define SK2C_THREADS 1024
+#define SK2C_TARGET (SK2C_SLOTS * 3 / 10)
+#define SK2C_LOADCAP (SK2C_SLOTS / 2)
+#define SK2C_SUB_BITS 16
+#define SK2C_MAX_PROBE 64
+#define SK2C_LOCK 0x80000000u
+
+static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
+
+// ---- shared with mk_skmer.hip (same definitions; kept local to this translation unit) -----------
+#define SK_M 11
+#define SK_MASK ((1u << (2 * SK_M)) - 1)
+__device__ __forceinline__ unsigned sk2_order_hash(unsigned mm) {
+  unsigned h = (mm * 0x2C9277B5u) & SK_MASK;
+  h ^= h >> 11;
+  h = (h * 0x1B873593u) & SK_MASK;
+  h ^= h >> 13;
+  h = (h * 0x0019660Du) & SK_MASK;
+  return h;
+}
+__device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
+__device__ __forceinline__ unsigned sk2_mmer(u64 w0, u64 w1, int q) {
+  u64 x;
+  if (q == 0) x = w0;
+  else if (q < 32) x = (w0 << (2 * q)) | (w1 >> (64 - 2 * q));
+  else x = w1 << (2 * (q - 32));
+  return (unsigned)(x >> (64 - 2 * SK_M));
+}
+
+struct Sk2Runs {
+  unsigned valid, starts;
+  u64 pos[4];
+};
+
+// Minimizer (over the 22 candidate 11-mers of the window's first 32 bases) of every window, runs.
+__device__ __forceinline__ Sk2Runs sk2_analyse(u64 w0, u64 w1, unsigned valid) {
+  constexpr int W = 22, NQ = SK2_R + W - 1, P = 16;
+  unsigned ord[NQ];
+  {
+    unsigned mm = sk2_mmer(w0, w1, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (q) {
+        const int pos = q + SK_M - 1;
+        const unsigned base = (unsigned)((pos < 32 ? (w0 >> (62 - 2 * pos)) : (w1 >> (62 - 2 * (pos - 32)))) & 3u);
+        mm = ((mm << 2) | base) & SK_MASK;
+      }
+      ord[q] = (sk2_order_hash(mm) << 6) | (unsigned)q;
+    }
+  }
+#pragma unroll
+  for (int step = 1; step < P; step <<= 1) {
+#pragma unroll
+    for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
+  }
+  Sk2Runs r;
+  r.valid = valid;
+  r.starts = 0;
+  r.pos[0] = r.pos[1] = r.pos[2] = r.pos[3] = 0;
+  unsigned prev_pos = 64;
+#pragma unroll
+  for (int j = 0; j < SK2_R; ++j) {
+    const bool ok = (valid >> j) & 1u;
+    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
+    r.starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
+    prev_pos = ok ? best : 64u;
+    r.pos[j / 10] |= (u64)best << (6 * (j % 10));
+  }
+  return r;
+}
+
+template <class F>
+__device__ __forceinline__ void sk2_walk(const Sk2Runs& r, u64 w0, u64 w1, F&& emit) {
+  unsigned todo = r.starts;
+  while (todo) {
+    const int j = __ffs(todo) - 1;
+    todo &= todo - 1;
+    const unsigned stop = (r.starts | ~r.valid) & ~((2u << j) - 1);
+    int nk = (stop ? (__ffs(stop) - 1) : SK2_R) - j;
+    const u64 pw = j < 10 ? r.pos[0] : (j < 20 ? r.pos[1] : (j < 30 ? r.pos[2] : r.pos[3]));
+    const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
+    const unsigned mm = sk2_mmer(w0, w1, (int)best);
+    int at = j;
+    while (nk > 0) {
+      const int take = nk < SK2_NKMAX ? nk : SK2_NKMAX;
+      emit(at, take, mm);
+      at += take;
+      nk -= take;
+    }
+  }
+}
+
+// Windows j = 0..31 whose k (<= 64) bases are clean; p0 is a multiple of 32.
+__device__ __forceinline__ unsigned sk2_valid32(const u64* __restrict__ bad, size_t p0, int k) {
+  const size_t bi = p0 >> 6;
+  u64 b_lo, b_hi;
+  if (p0 & 63) {
+    const u64 x0 = bad[bi], x1 = bad[bi + 1], x2 = bad[bi + 2];
+    b_lo = (x0 >> 32) | (x1 << 32);
+    b_hi = (x1 >> 32) | (x2 << 32);
+  } else {
+    b_lo = bad[bi];
+    b_hi = bad[bi + 1];
+  }
+  const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
+  unsigned v = 0;
+#pragma unroll
+  for (int j = 0; j < SK2_R; ++j) {
+    const u64 win = (b_lo >> j) | (j ? (b_hi << (64 - j)) : 0ull);  // bad bits j .. j+63
+    v |= ((win & kmask) == 0) ? (1u << j) : 0u;
+  }
+  return v;
+}
+
+struct __attribute__((aligned(32))) Sk2Rec {
+  u64 r0, r1, r2, nk;
+};
+
+__device__ __forceinline__ Sk2Rec sk2_make_record(u64 w0, u64 w1, u64 w2, u64 w3, int jstart, int nk, int k) {
+  const int s = 2 * jstart;
+  Sk2Rec r;
+  r.r0 = s ? ((w0 << s) | (w1 >> (64 - s))) : w0;
+  r.r1 = s ? ((w1 << s) | (w2 >> (64 - s))) : w1;
+  r.r2 = s ? ((w2 << s) | (w3 >> (64 - s))) : w2;
+  const int bits = 2 * (nk + k - 1);  // 66 .. 142
+  if (bits <= 128) { r.r2 = 0; if (bits < 128) r.r1 &= ~0ull << (128 - bits); }
+  else r.r2 &= ~0ull << (192 - bits);
+  r.nk = (u64)nk;
+  return r;
+}
+
+// ------------------------------------------------------------------------------ hist / scatter
+__global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                                  MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
+                                                                  u64* __restrict__ khist, int p1_log2, int k,
+                                                                  size_t nthreads_total) {
+  __shared__ unsigned lh[SK2_MAX_P1];
+  __shared__ unsigned lk[SK2_MAX_P1];
+  const unsigned p1 = 1u << p1_log2;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) { lh[i] = 0; lk[i] = 0; }
+  __syncthreads();
+  const size_t seq_len = info->seq_len;
+  u64 mine = 0, recs = 0;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t p0 = t * SK2_R;
+    if (p0 >= seq_len) break;
+    const u64 w0 = codes[t], w1 = codes[t + 1];
+    const Sk2Runs r = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
+    sk2_walk(r, w0, w1, [&](int, int nk, unsigned mm) {
+      const unsigned b = sk2_bucket(mm, p1_log2);
+      atomicAdd(&lh[b], 1u);
+      atomicAdd(&lk[b], (unsigned)nk);
+      mine += (u64)nk;
+      ++recs;
+    });
+  }
+  __syncthreads();
+  for (unsigned b = threadIdx.x; b < p1; b += blockDim.x) {
+    const unsigned v = lh[b];
+    if (v) {
+      atomicAdd(&hist[b], (u64)v);
+      atomicAdd(&khist[b], (u64)lk[b]);
+    }
+  }
+  wave_add(&info->exotic, mine);  // these windows are counted outside the packed-key table: "by reference" totals
+  wave_add(&info->records, recs);
+}
+
+__global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                                     const MkChunkInfo* __restrict__ info,
+                                                                     u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
+                                                                     int p1_log2, int k, size_t ntiles) {
+  __shared__ unsigned lh[SK2_MAX_P1];
+  __shared__ u64 gbase[SK2_MAX_P1];
+  constexpr int NB = SK2_MAX_P1 / SK2_SCAT_THREADS;
+  const unsigned p1 = 1u << p1_log2;
+  const size_t seq_len = info->seq_len;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t t = tile * SK2_SCAT_THREADS + threadIdx.x;
+    const size_t p0 = t * SK2_R;
+    Sk2Runs runs;
+    runs.valid = 0;
+    runs.starts = 0;
+    u64 w0 = 0, w1 = 0;
+    if (p0 < seq_len) {
+      w0 = codes[t];
+      w1 = codes[t + 1];
+      runs = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
+      sk2_walk(runs, w0, w1, [&](int, int, unsigned mm) { atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u); });
+    }
+    __syncthreads();
+    {
+      unsigned v[NB];
+      u64 r[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        v[i] = b < p1 ? lh[b] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        if (b < p1) { gbase[b] = r[i]; lh[b] = 0; }
+      }
+    }
+    __syncthreads();
+    if (runs.starts) {
+      const u64 w2 = codes[t + 2], w3 = codes[t + 3];
+      sk2_walk(runs, w0, w1, [&](int jstart, int nk, unsigned mm) {
+        const unsigned b = sk2_bucket(mm, p1_log2);
+        part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
+      });
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------- count
+__device__ __forceinline__ unsigned sk2c_hash(u64 hi, u64 lo) {
+  unsigned h = (unsigned)hi * 0x9E3779B1u ^ (unsigned)(hi >> 32) * 0x85EBCA77u;
+  h ^= ((unsigned)lo * 0xC2B2AE3Du ^ (unsigned)(lo >> 32) * 0x27D4EB2Fu) + (h << 6) + (h >> 2);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 16;
+  return h;
+}
+
+// Insert one 128-bit key (see the protocol in the header).
+__device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
+  unsigned slot = h >> 20;  // SK2C_SLOTS == 4096
+  for (int probe = 0; probe < SK2C_MAX_PROBE;) {
+    unsigned c = __hip_atomic_load(&tcnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (c == 0) {
+      c = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
+      if (c == 0) {  // ours: write the key, then publish with count 1
+        thi[slot] = hi;
+        tlo[slot] = lo;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
+        return;
+      }
+    }
+    if (c & SK2C_LOCK) continue;  // another lane is writing this slot: look again
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (thi[slot] == hi && tlo[slot] == lo) {
+      atomicAdd(&tcnt[slot], 1u);
+      return;
+    }
+    slot = (slot + 1) & (SK2C_SLOTS - 1);
+    ++probe;
+  }
+  atomicOr(ovf, 1u);
+}
+
+__global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
+                                                               const u64* __restrict__ kstart, u64* __restrict__ nsurv,
+                                                               MkChunkInfo* __restrict__ info, u64 min_count,
+                                                               u64* __restrict__ out_hi, u64* __restrict__ out_lo,
+                                                               u64* __restrict__ out_cnt, int k, unsigned p1,
+                                                               double dup_hint, double nk_hint) {
+  __shared__ u64 thi[SK2C_SLOTS];
+  __shared__ u64 tlo[SK2C_SLOTS];
+  __shared__ unsigned tcnt[SK2C_SLOTS];
+  __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
+  for (unsigned i = threadIdx.x; i < SK2C_SLOTS; i += blockDim.x) tcnt[i] = 0;
+  if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
+  __syncthreads();
+  unsigned par = 0;
+  const int lane = threadIdx.x & 63;
+  const u64 lomask = (k >= 64) ? ~0ull : (~0ull << (128 - 2 * k));
+  u64 distinct_total = 0, survivors_total = 0, nerr = 0;
+  for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
+    const u64 lo_r = start[b], n = start[b + 1] - lo_r;
+    u64* __restrict__ my_hi = out_hi + kstart[b];
+    u64* __restrict__ my_lo = out_lo + kstart[b];
+    u64* __restrict__ my_cnt = out_cnt + kstart[b];
+    unsigned emitted = 0;
+    if (n >> 27) {
+      ++nerr;
+    } else if (n) {
+      int s0 = 0;
+      {
+        const double expect = (double)n * nk_hint / (dup_hint > 1.0 ? dup_hint : 1.0);
+        while (s0 < SK2C_SUB_BITS && expect / (double)(1u << s0) > (double)SK2C_TARGET) ++s0;
+        if ((double)n * SK2_NKMAX <= (double)SK2C_LOADCAP) s0 = 0;
+      }
+      int s = s0;
+      unsigned idx = 0;
+      const Sk2Rec* __restrict__ src = part + lo_r;
+      for (;;) {
+        const unsigned sel_shift = SK2C_SUB_BITS - s;
+        unsigned* const ovf = &s_overflow[par];
+        for (u64 j = threadIdx.x; j < n; j += SK2C_THREADS) {
+          const Sk2Rec rec = src[j];
+          const int nk = (int)rec.nk;
+          u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
+          for (int i = 0; i < nk; ++i) {
+            const u64 hi = x0, lo = x1 & lomask;
+            x0 = (x0 << 2) | (x1 >> 62);
+            x1 = (x1 << 2) | (x2 >> 62);
+            x2 <<= 2;
+            const unsigned h = sk2c_hash(hi, lo);
+            if (s && ((h & ((1u << SK2C_SUB_BITS) - 1)) >> sel_shift) != idx) continue;
+            sk2c_insert(thi, tlo, tcnt, ovf, hi, lo, h);
+          }
+          if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
+        __syncthreads();  // A
+        const bool over = s_overflow[par] != 0;
+        if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
+        {
+          constexpr int PER = SK2C_SLOTS / SK2C_THREADS;
+          u64 eh[PER], el[PER];
+          unsigned ec[PER];
+          unsigned mine = 0, occ = 0;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const unsigned i = q * SK2C_THREADS + threadIdx.x;
+            ec[q] = tcnt[i];
+            eh[q] = thi[i];
+            el[q] = tlo[i];
+            tcnt[i] = 0;
+            occ += ec[q] != 0;
+            if (over || (u64)ec[q] < min_count) ec[q] = 0;
+            mine += ec[q] != 0;
+          }
+          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
+          if (mine) {
+            const unsigned at = emitted + atomicAdd(&s_emit[par], mine);
+            unsigned o = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              if (ec[q]) {
+                my_hi[at + o] = eh[q];
+                my_lo[at + o] = el[q];
+                my_cnt[at + o] = ec[q];
+                ++o;
+              }
+            }
+          }
+        }
+        __syncthreads();  // B
+        emitted += s_emit[par];
+        distinct_total += s_distinct[par];
+        par ^= 1;
+        if (over) {
+          if (s >= SK2C_SUB_BITS) { ++nerr; break; }
+          s += 1;
+          idx <<= 1;
+        } else {
+          while (s > s0 && (idx & 1u)) { idx >>= 1; --s; }
+          if (s == s0) {
+            ++idx;
+            if (idx >= (1u << s0)) break;
+          } else {
+            ++idx;
+          }
+        }
+      }
+    }
+    if (threadIdx.x == 0) nsurv[b] = emitted;
+    survivors_total += emitted;
+  }
+  if (threadIdx.x == 0) {
+    if (distinct_total) atomicAdd(&info->distinct, distinct_total);
+    if (survivors_total) atomicAdd(&info->survivors_ref, survivors_total);
+    if (nerr) atomicAdd(&info->errors, nerr);
+  }
+}
+
+// ------------------------------------------------------------------------------------ launcher
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2);  // mk_part.hip
+
+int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
+  if (seq_len == 0) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  const int k = c->k;
+  int p1_log2 = 8;
+  while (p1_log2 < 13 && (seq_len >> p1_log2) > 8192) ++p1_log2;
+  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= 13) p1_log2 = v; }
+  c->p1_log2 = p1_log2;
+  const size_t p1 = (size_t)1 << p1_log2;
+  int rc;
+  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(Sk2Rec))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_keys, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_keys2, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_cnts, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  u64* hist = (u64*)c->part_meta.p;
+  u64* start = hist + p1;
+  u64* cursor = start + p1 + 1;
+  u64* khist = cursor + p1;
+  u64* kstart = khist + p1;
+  u64* kcursor = kstart + p1 + 1;
+  u64* nsurv = kcursor + p1;
+  MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
+  const size_t threads = div_up(seq_len, SK2_R), tiles = div_up(threads, SK2_HIST_THREADS);
+  const size_t stiles = div_up(threads, SK2_SCAT_THREADS);
+  mk_prof_begin(c, MK_K_PART);
+  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK2_HIST_THREADS), 0, c->stream,
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads);
+  mk_launch_part_scan(c, hist, start, cursor, p1_log2);
+  hipLaunchKernelGGL(mk_sk2_scatter_k, dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK2_SCAT_THREADS), 0,
+                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (Sk2Rec*)c->part.p, p1_log2, k,
+                     stiles);
+  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2);
+  mk_prof_end(c);
+  mk_prof_begin(c, MK_K_COUNT);
+  {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
+    hipLaunchKernelGGL(mk_sk2_count_k, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
+                       (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                       (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
+  }
+  mk_prof_end(c);
+  MK_HIP(hipGetLastError());
+  c->surv_regions = 2;  // {hi, lo, count} triples per bucket
+  return MK_OK;
+}

@@ -142,16 +142,33 @@ __device__ __forceinline__ unsigned ld_u8_agent(const uint8_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ u64 poly_hash(const uint8_t* __restrict__ s, int k) {
+// The k-mer text comes through an accessor get(i) -> byte i, so the same code serves text held in
+// memory (chunk stream, staging buffer) and text decoded on the fly from packed keys.
+struct BytesAt {
+  const uint8_t* p;
+  __device__ __forceinline__ unsigned operator()(int i) const { return p[i]; }
+};
+struct Key128Text {  // 2-bit packed, left-aligned {hi, lo}: base i of the k-mer
+  u64 hi, lo;
+  __device__ __forceinline__ unsigned operator()(int i) const {
+    const unsigned code = (unsigned)((i < 32 ? hi >> (62 - 2 * i) : lo >> (62 - 2 * (i - 32))) & 3u);
+    return (unsigned)"ACGT"[code];
+  }
+};
+
+template <class Get>
+__device__ __forceinline__ u64 poly_hash_of(const Get& get, int k) {
   u64 h = 0;
-  for (int i = 0; i < k; ++i) h = h * MK_POLY_B + s[i];
+  for (int i = 0; i < k; ++i) h = h * MK_POLY_B + get(i);
   return mk_mix64(h);
 }
 
-__device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, uint8_t* __restrict__ arena,
-                                           const uint8_t* __restrict__ str, int k, u64 add, u64 arena_base,
-                                           u64* __restrict__ new_rows) {
-  const u64 h = poly_hash(str, k);
+__device__ __forceinline__ u64 poly_hash(const uint8_t* __restrict__ s, int k) { return poly_hash_of(BytesAt{s}, k); }
+
+template <class Get>
+__device__ __forceinline__ bool upsert_ref_of(MkSlot* __restrict__ run, u64 mask, uint8_t* __restrict__ arena, const Get& get,
+                                              int k, u64 add, u64 arena_base, u64* __restrict__ new_rows) {
+  const u64 h = poly_hash_of(get, k);
   const u64 tag = (h >> 41) << REF_POS_BITS;
   u64 slot = h & mask;
   u64 my_row = MK_EMPTY;
@@ -161,7 +178,8 @@ __device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, u
       if (my_row == MK_EMPTY) {
         my_row = arena_base + atomicAdd(new_rows, 1ull);
         uint8_t* dst = arena + my_row * (u64)k;
-        for (int i = 0; i < k; ++i) __hip_atomic_store(dst + i, str[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < k; ++i)
+          __hip_atomic_store(dst + i, (uint8_t)get(i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence();
       }
       cur = atomicCAS(&run[slot].key, MK_EMPTY, tag | my_row);
@@ -173,7 +191,7 @@ __device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, u
     if ((cur & ~REF_POS_MASK) == tag && my_row == MK_EMPTY) {
       const uint8_t* other = arena + (cur & REF_POS_MASK) * (u64)k;
       bool same = true;
-      for (int i = 0; i < k && same; ++i) same = ld_u8_agent(other + i) == str[i];
+      for (int i = 0; i < k && same; ++i) same = ld_u8_agent(other + i) == get(i);
       if (same) {
         atomicAdd(&run[slot].cnt, add);
         return false;
@@ -181,6 +199,37 @@ __device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, u
     }
     slot = (slot + 1) & mask;
   }
+}
+
+__device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, uint8_t* __restrict__ arena,
+                                           const uint8_t* __restrict__ str, int k, u64 add, u64 arena_base,
+                                           u64* __restrict__ new_rows) {
+  return upsert_ref_of(run, mask, arena, BytesAt{str}, k, add, arena_base, new_rows);
+}
+
+// Survivors of the partitioned 33..64-mer path: {hi, lo, count} per bucket region (kstart/nsurv as
+// for mk_import_regions_k) -> by-reference running table. One wave per bucket.
+__global__ void mk_import_ref128_regions_k(const u64* __restrict__ hi, const u64* __restrict__ lo, const u64* __restrict__ cnts,
+                                           const u64* __restrict__ kstart, const u64* __restrict__ nsurv, size_t p1, int k,
+                                           MkSlot* __restrict__ run, u64 run_mask, uint8_t* __restrict__ arena,
+                                           u64 arena_base, u64* __restrict__ new_rows) {
+  const int lane = threadIdx.x & 63;
+  for (size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < p1; b += (size_t)gridDim.x * (blockDim.x >> 6)) {
+    const u64 base = kstart[b], n = nsurv[b];
+    for (u64 i = lane; i < n; i += 64)
+      upsert_ref_of(run, run_mask, arena, Key128Text{hi[base + i], lo[base + i]}, k, cnts[base + i], arena_base, new_rows);
+  }
+}
+
+int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,
+                                    const uint64_t* kstart, const uint64_t* nsurv, size_t p1) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_import_ref128_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream,
+                     (const u64*)hi, (const u64*)lo, (const u64*)cnts, (const u64*)kstart, (const u64*)nsurv, p1, c->k,
+                     (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1), (uint8_t*)c->arena.p, (u64)c->run_ref_rows,
+                     &info->new_rows_ref);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
 }
 
 // Survivors of the by-reference chunk table -> running by-reference table. Within one launch
