@@ -27,8 +27,8 @@
 #define SK2_NKMAX 8
 #define SK2C_SLOTS 4096
 #define SK2C_THREADS 1024
-#define SK2C_TARGET (SK2C_SLOTS * 3 / 10)
-#define SK2C_LOADCAP (SK2C_SLOTS / 2)
+#define SK2C_TARGET (SK2C_SLOTS * 6 / 10)
+#define SK2C_LOADCAP (SK2C_SLOTS * 3 / 4)
 #define SK2C_SUB_BITS 16
 #define SK2C_MAX_PROBE 64
 #define SK2C_LOCK 0x80000000u
@@ -329,16 +329,57 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
         unsigned* const ovf = &s_overflow[par];
         for (u64 j = threadIdx.x; j < n; j += SK2C_THREADS) {
           const Sk2Rec rec = src[j];
-          const int nk = (int)rec.nk;
-          u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
-          for (int i = 0; i < nk; ++i) {
-            const u64 hi = x0, lo = x1 & lomask;
-            x0 = (x0 << 2) | (x1 >> 62);
-            x1 = (x1 << 2) | (x2 >> 62);
-            x2 <<= 2;
-            const unsigned h = sk2c_hash(hi, lo);
-            if (s && ((h & ((1u << SK2C_SUB_BITS) - 1)) >> sel_shift) != idx) continue;
-            sk2c_insert(thi, tlo, tcnt, ovf, hi, lo, h);
+          const int nk = (int)rec.nk;  // <= SK2_NKMAX
+          u64 khi[SK2_NKMAX], klo[SK2_NKMAX];
+          unsigned hh[SK2_NKMAX], st[SK2_NKMAX];
+          unsigned alive = 0;
+          {
+            u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
+#pragma unroll
+            for (int u = 0; u < SK2_NKMAX; ++u) {
+              khi[u] = x0;
+              klo[u] = x1 & lomask;
+              x0 = (x0 << 2) | (x1 >> 62);
+              x1 = (x1 << 2) | (x2 >> 62);
+              x2 <<= 2;
+              hh[u] = sk2c_hash(khi[u], klo[u]);
+              const bool mine = u < nk && (!s || ((hh[u] & ((1u << SK2C_SUB_BITS) - 1)) >> sel_shift) == idx);
+              alive |= mine ? (1u << u) : 0u;
+            }
+          }
+          // batched first probe: states of the 8 home slots, claims of the free ones, then the key
+          // compares of the occupied ones; whatever is left (collision, or a slot mid-write) takes
+          // the serial loop, which starts again at the home slot
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u)
+            st[u] = ((alive >> u) & 1u) ? __hip_atomic_load(&tcnt[hh[u] >> 20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            if (((alive >> u) & 1u) && st[u] == 0) {
+              const unsigned slot = hh[u] >> 20;
+              st[u] = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
+              if (st[u] == 0) {
+                thi[slot] = khi[u];
+                tlo[slot] = klo[u];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
+                alive &= ~(1u << u);
+              }
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          u64 oh[SK2_NKMAX], ol[SK2_NKMAX];
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            const bool look = ((alive >> u) & 1u) && !(st[u] & SK2C_LOCK);
+            oh[u] = look ? thi[hh[u] >> 20] : 0ull;
+            ol[u] = look ? tlo[hh[u] >> 20] : 0ull;
+          }
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            if (!((alive >> u) & 1u)) continue;
+            if (!(st[u] & SK2C_LOCK) && oh[u] == khi[u] && ol[u] == klo[u]) atomicAdd(&tcnt[hh[u] >> 20], 1u);
+            else sk2c_insert(thi, tlo, tcnt, ovf, khi[u], klo[u], hh[u]);
           }
           if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
