@@ -78,14 +78,16 @@ __global__ __launch_bounds__(PART_THREADS) void mk_part_hist_k(const u64* __rest
 }
 
 // -------------------------------------------------------------------------------- 2 scan
+// `div` > 1 scans ceil(hist/div) instead of hist: a bucket with m k-mers has at most m/c entries with
+// count >= c, which is all the room its survivor region needs.
 __global__ __launch_bounds__(1024) void mk_part_scan_k(const u64* __restrict__ hist, u64* __restrict__ start,
-                                                       u64* __restrict__ cursor, int p1_log2) {
+                                                       u64* __restrict__ cursor, int p1_log2, u64 div) {
   __shared__ u64 sums[1024];
   const unsigned p1 = 1u << p1_log2;
   const unsigned per = (p1 + 1023) / 1024;
   const unsigned lo = threadIdx.x * per;
   u64 acc = 0;
-  for (unsigned i = lo; i < lo + per && i < p1; ++i) acc += hist[i];
+  for (unsigned i = lo; i < lo + per && i < p1; ++i) acc += (hist[i] + div - 1) / div;
   sums[threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(1024) void mk_part_scan_k(const u64* __restrict__ h
   for (unsigned i = lo; i < lo + per && i < p1; ++i) {
     start[i] = run;
     cursor[i] = run;
-    run += hist[i];
+    run += (hist[i] + div - 1) / div;
   }
 }
 
@@ -351,8 +353,8 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
   if (threadIdx.x == 0) atomicAdd(&info->distinct, distinct_total);
 }
 
-void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2) {
-  hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, start, cursor, p1_log2);
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div) {
+  hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, start, cursor, p1_log2, div ? div : 1);
 }
 
 // ------------------------------------------------------------------------------ launcher
@@ -382,7 +384,7 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL((mk_part_hist_k<2, 32, 1>), dim3(grid), dim3(PART_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads, c->canonical);
-    hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2);
+    hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2, (u64)1);
     hipLaunchKernelGGL((mk_part_scatter_k<2, 32, 1>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SCAT_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (u64*)c->part.p, p1_log2,
                        c->k, stiles, dbg, c->canonical);
@@ -392,7 +394,7 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL((mk_part_hist_k<5, 12, 3>), dim3(grid), dim3(PART_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, hist, p1_log2, c->k, threads, c->canonical);
-    hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2);
+    hipLaunchKernelGGL(mk_part_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, start, cursor, p1_log2, (u64)1);
     hipLaunchKernelGGL((mk_part_scatter_k<5, 12, 3>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SCAT_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (u64*)c->part.p, p1_log2,
                        c->k, stiles, dbg, c->canonical);

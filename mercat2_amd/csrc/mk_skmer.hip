@@ -554,17 +554,18 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
 }
 
 // ------------------------------------------------------------------------------ launcher
-void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2);  // mk_part.hip
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div);  // mk_part.hip
 
 template <int W>
 static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, u64* hist, u64* start, u64* cursor, u64* khist) {
+  (void)khist;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const size_t threads = div_up(seq_len, SK_R), tiles = div_up(threads, SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end
   hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical);
-  mk_launch_part_scan(c, hist, start, cursor, p1_log2);
+  mk_launch_part_scan(c, hist, start, cursor, p1_log2, 1);
   hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (ulonglong2*)c->part.p, p1_log2,
                      c->k, nkmax, stiles, c->canonical);
@@ -594,8 +595,11 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   // worst case one record per window
   if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(ulonglong2))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->surv_keys, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->surv_cnts, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  // a bucket with m k-mers has at most ceil(m / min_count) survivors: that bounds its region
+  const u64 surv_div = min_count > 1 ? (u64)min_count : 1;
+  const size_t surv_cap = seq_len / surv_div + p1 + 64;
+  if ((rc = mk_buf_reserve(c, c->surv_keys, surv_cap * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
   u64* hist = (u64*)c->part_meta.p;
   u64* start = hist + p1;
   u64* cursor = start + p1 + 1;
@@ -614,7 +618,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
       c->err = "mk_launch_count_superkmer: k out of range";
       return MK_ERR_ARG;
   }
-  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2);
+  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2, surv_div);
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {

@@ -448,7 +448,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
 }
 
 // ------------------------------------------------------------------------------------ launcher
-void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2);  // mk_part.hip
+void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div);  // mk_part.hip
 
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   if (seq_len == 0) return MK_OK;
@@ -462,9 +462,11 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(Sk2Rec))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->surv_keys, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->surv_keys2, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->surv_cnts, (seq_len + 64) * sizeof(u64))) != MK_OK) return rc;
+  const u64 surv_div = min_count > 1 ? (u64)min_count : 1;  // <= ceil(m / min_count) survivors among m k-mers
+  const size_t surv_cap = seq_len / surv_div + p1 + 64;
+  if ((rc = mk_buf_reserve(c, c->surv_keys, surv_cap * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_keys2, surv_cap * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
   u64* hist = (u64*)c->part_meta.p;
   u64* start = hist + p1;
   u64* cursor = start + p1 + 1;
@@ -478,11 +480,11 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   mk_prof_begin(c, MK_K_PART);
   hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK2_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads);
-  mk_launch_part_scan(c, hist, start, cursor, p1_log2);
+  mk_launch_part_scan(c, hist, start, cursor, p1_log2, 1);
   hipLaunchKernelGGL(mk_sk2_scatter_k, dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK2_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (Sk2Rec*)c->part.p, p1_log2, k,
                      stiles);
-  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2);
+  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2, surv_div);
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {
