@@ -286,8 +286,12 @@ static int grow_run_ref(mk_ctx* c, size_t need_rows) {
 }
 
 // --------------------------------------------------------------------------- the pipeline
+// d_raw may be unaligned: the fast parser reads from the 16-byte boundary below it and ignores the
+// bytes in front; only the (rare) general-parser fallback needs an aligned copy.
 static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
   int rc;
+  const size_t begin = (size_t)((uintptr_t)d_raw & 15);
+  const uint8_t* d_al = d_raw - begin;
   MK_HIP(hipSetDevice(c->device));
   MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
   if ((rc = mk_buf_reserve(c, c->seq, n + 256)) != MK_OK) return rc;
@@ -301,7 +305,12 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   for (int attempt = 0; attempt < 2; ++attempt) {
     const bool fast = c->use_fast_parse && attempt == 0;
     const bool fused = fast && packed && c->alphabet == MK_ALPHABET_NT2;  // the nt pack rides on the parser's LDS image
-    if ((rc = fast ? mk_launch_fparse(c, d_raw, n, fused) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
+    if (!fast && begin) {  // aligned copy for the general transducer
+      if ((rc = mk_buf_reserve(c, c->raw, n + 64)) != MK_OK) return rc;
+      MK_HIP(hipMemcpyAsync(c->raw.p, d_raw, n, hipMemcpyDeviceToDevice, c->stream));
+      d_raw = (const uint8_t*)c->raw.p;
+    }
+    if ((rc = fast ? mk_launch_fparse(c, d_al, begin, n, fused) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
     if (packed && !fused && (rc = mk_launch_pack(c, n)) != MK_OK) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
     if (!fast || !c->h_info->parse_fallback) break;
@@ -424,7 +433,7 @@ extern "C" int mk_count_device(mk_ctx* c, const uint8_t* d_text, size_t n, uint6
   if (!c) return MK_ERR_ARG;
   if (c->in_chunk) { c->err = "mk_count_device: a chunk is open"; return MK_ERR_STATE; }
   if (n && !d_text) { c->err = "mk_count_device: d_text is NULL"; return MK_ERR_ARG; }
-  if (((uintptr_t)d_text & 15) == 0) return process_chunk(c, d_text, n, min_count);
+  if (((uintptr_t)d_text & 15) == 0 || c->use_fast_parse) return process_chunk(c, d_text, n, min_count);
   int rc = mk_chunk_begin(c);
   if (!rc) rc = mk_chunk_feed_device(c, d_text, n);
   if (rc) { c->in_chunk = false; return rc; }

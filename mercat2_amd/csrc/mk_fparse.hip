@@ -34,17 +34,18 @@ struct FpEntry {  // per wave summary / scan result
   unsigned b;     // summ: cnt0 | cnt1 << 16
 };
 
-// Class masks of 16 bytes. Bytes at or beyond `n` behave like newlines (they emit nothing).
-__device__ __forceinline__ uint4 classify16(const uint8_t* __restrict__ raw, size_t pos, size_t n, unsigned& nl,
+// Class masks of 16 bytes. Bytes outside [begin, n) behave like newlines (they emit nothing): `raw` is
+// the 16-byte-aligned address at or below the chunk's first byte, `begin` the chunk's offset in it.
+__device__ __forceinline__ uint4 classify16(const uint8_t* __restrict__ raw, size_t pos, size_t begin, size_t n, unsigned& nl,
                                             unsigned& gt, unsigned& st, unsigned& low, unsigned& hi) {
   uint4 v;
-  if (pos + 16 <= n) {
+  if (pos + 16 <= n && pos >= begin) {
     v = *reinterpret_cast<const uint4*>(raw + pos);
   } else {
     unsigned w0 = 0, w1 = 0, w2 = 0, w3 = 0;  // static indexing only (no scratch): bytes past n read as '\n'
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const unsigned c = (pos + j < n) ? (unsigned)raw[pos + j] : 10u;
+      const unsigned c = (pos + j < n && pos + j >= begin) ? (unsigned)raw[pos + j] : 10u;
       const unsigned sh = 8 * (j & 3);
       if (j < 4) w0 |= c << sh; else if (j < 8) w1 |= c << sh; else if (j < 12) w2 |= c << sh; else w3 |= c << sh;
     }
@@ -112,19 +113,19 @@ __device__ __forceinline__ unsigned wave_step(unsigned nl, unsigned gt, unsigned
   return __shfl(hout, 63);
 }
 
-__global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __restrict__ raw, size_t n, size_t nwaves,
+__global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __restrict__ raw, size_t begin, size_t n, size_t nwaves,
                                                              FpEntry* __restrict__ entries, MkChunkInfo* __restrict__ info) {
   const size_t wave = (size_t)blockIdx.x * FP_WAVES + (threadIdx.x >> 6);
   if (wave >= nwaves) return;
   const int lane = threadIdx.x & 63;
   const size_t base = wave * FP_WAVE_BYTES;
-  unsigned prev_nl = (base == 0) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
+  unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
   unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0, nhi = 0;
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
     unsigned nl, gt, st, low, hi;
-    (void)classify16(raw, pos, n, nl, gt, st, low, hi);
+    (void)classify16(raw, pos, begin, n, nl, gt, st, low, hi);
     nhi += hi;
     unsigned out, sep, bl, last_nl;
     const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
   }
 }
 
-__global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __restrict__ raw, size_t n, size_t nwaves,
+__global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __restrict__ raw, size_t begin, size_t n, size_t nwaves,
                                                              FpScan* __restrict__ scan, uint8_t* __restrict__ seq,
                                                              MkChunkInfo* __restrict__ info, u64* __restrict__ codes,
                                                              u64* __restrict__ bad) {
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   const FpScan sc = scan[wave];
   const unsigned shift = (unsigned)(sc.off & 15);
   uint8_t* __restrict__ lds = stage[wv] + 64;
-  unsigned prev_nl = (base == 0) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
+  unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
   unsigned state = sc.st;
   unsigned filled = 0;   // bytes emitted so far by this wave
   unsigned nsym = 0;
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
     unsigned nl, gt, st, low, hi;
-    const uint4 v = classify16(raw, pos, n, nl, gt, st, low, hi);
+    const uint4 v = classify16(raw, pos, begin, n, nl, gt, st, low, hi);
     unsigned out, sep, bl, last_nl;
     state = wave_step(nl, gt, st, low, prev_nl, state, out, sep, bl, last_nl);
     prev_nl = last_nl;
@@ -390,7 +391,9 @@ __global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict
 }
 
 // Returns MK_OK after enqueueing; info->parse_fallback != 0 afterwards means "re-parse with the general kernels".
-int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n, bool fuse_pack_nt) {
+// d_raw is 16-byte aligned; the chunk is its bytes [begin, begin + len) (begin < 16).
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, bool fuse_pack_nt) {
+  const size_t n = begin + len;
   u64* codes = fuse_pack_nt ? (u64*)c->codes.p : nullptr;
   u64* bad = fuse_pack_nt ? (u64*)c->bad.p : nullptr;
   if (fuse_pack_nt) {  // partial words are OR-ed in: start from zero (padding words included)
@@ -399,7 +402,7 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n, bool fuse_pack_n
     MK_HIP(hipMemsetAsync(c->bad.p, 0, bad_words * sizeof(u64), c->stream));
     if (n == 0) MK_HIP(hipMemsetAsync(c->bad.p, 0xFF, 4 * sizeof(u64), c->stream));
   }
-  if (n == 0) return MK_OK;
+  if (len == 0) return MK_OK;
   const size_t nwaves = (n + FP_WAVE_BYTES - 1) / FP_WAVE_BYTES;
   const size_t e_bytes = (nwaves * sizeof(FpEntry) + 15) & ~(size_t)15;
   int rc = mk_buf_reserve(c, c->tile_maps, e_bytes + nwaves * sizeof(FpScan));
@@ -409,9 +412,9 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t n, bool fuse_pack_n
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const unsigned blocks = (unsigned)((nwaves + FP_WAVES - 1) / FP_WAVES);
   mk_prof_begin(c, MK_K_PARSE);
-  hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, entries, info);
+  hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, entries, info);
   hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info);
-  hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, n, nwaves, scan,
+  hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, scan,
                      (uint8_t*)c->seq.p, info, codes, bad);
   hipLaunchKernelGGL(mk_fparse_total, dim3(1), dim3(1024), 0, c->stream, (const FpScan*)scan, nwaves, info, bad);
   mk_prof_end(c);

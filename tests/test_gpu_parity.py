@@ -373,3 +373,23 @@ def test_low_complexity_and_repeats():
             kmers, counts = ctx.export()
         okm, ocn = c_oracle.count(data, k, 10)
         assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
+
+
+def test_count_device_unaligned_offsets():
+    """mk_count_device on text resident in HBM at every 16-byte misalignment (the fast parser reads
+    from the aligned address below and ignores the bytes in front) == the host-fed result."""
+    import torch
+    data = native.synth_reads(20_000, 71, 3_000, 150, 72).tobytes() + read_input("edge_lengths.fa")
+    odd = read_input("edge_ws.fa")  # blanks in sequence lines: general-parser fallback + aligned copy
+    for payload, k in [(data, 21), (odd, 5)]:
+        with native.Counter(k, native.ALPHABET_NT2) as ref:
+            ref.count_chunk(payload, 1)
+            want = ref.to_dict()
+        for off in (0, 1, 7, 15):
+            buf = torch.zeros(len(payload) + 64, dtype=torch.uint8, device="cuda")
+            buf[:16] = ord(">")  # garbage in front of the chunk must be ignored
+            buf[off:off + len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            with native.Counter(k, native.ALPHABET_NT2) as ctx:
+                ctx.count_device(buf.data_ptr() + off, len(payload), 1)
+                assert ctx.to_dict() == want, (k, off)
