@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=READS, help="reads per rank (default: the BASELINE workload)")
     ap.add_argument("--k", type=int, default=K)
+    ap.add_argument("--genome", type=int, default=GENOME, help="genome length of the synthetic sample")
+    ap.add_argument("--genome-seed", type=int, default=GENOME_SEED)
+    ap.add_argument("--read-seed", type=int, default=READ_SEED)
+    ap.add_argument("--sub-ppm", type=int, default=0, help="per-base substitution rate, parts per million (S2e: 10000)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "2")),
                     help="engine contexts (HIP streams) per GPU; chunks are dealt round-robin and counted "
@@ -110,7 +114,7 @@ def main():
     # ---- synthetic input: generate on the host, cut like the reference Chunker, move to HBM
     k = args.k
     t0 = time.perf_counter()
-    host = native.synth_reads(GENOME, GENOME_SEED, args.reads, READ_LEN, READ_SEED, 0, rank * args.reads)
+    host = native.synth_reads(args.genome, args.genome_seed, args.reads, READ_LEN, args.read_seed, args.sub_ppm, rank * args.reads)
     offs = chunk_offsets(host, CHUNK_MIB * 1024 * 1024) if host.nbytes >= CHUNK_MIB * 1024 * 1024 else [0, host.nbytes]
     text = torch.from_numpy(host).to(dev)
     gen_s = time.perf_counter() - t0
@@ -124,7 +128,7 @@ def main():
     ctx = ctxs[0]
     pool = ThreadPoolExecutor(nctx) if nctx > 1 else None
     key_bits = 2 * k
-    out_cap = 2 * GENOME + 1024  # distinct forward-strand k-mers of both strands, upper bound
+    out_cap = (2 * args.genome + 1024) * (1 if args.sub_ppm == 0 else 12)  # distinct forward-strand k-mers of both strands, upper bound
     out_keys = torch.empty(out_cap, dtype=torch.int64, device=dev)
     out_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev)
     base_ptr = text.data_ptr()
@@ -210,8 +214,9 @@ def main():
             "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "S2: %d reads x %d bp per GPU from a %d bp genome, k=%d, -c %d, -s %d (%d chunks), "
-                                   "forward-strand keys" % (args.reads, READ_LEN, GENOME, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1),
+            "config": {"workload": "%s: %d reads x %d bp per GPU from a %d bp genome, k=%d, -c %d, -s %d (%d chunks), "
+                                   "forward-strand keys" % ("S2" if (args.reads, args.genome, k, args.sub_ppm) == (READS, GENOME, K, 0) else "custom",
+                                                            args.reads, READ_LEN, args.genome, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1),
                        "reads_per_gpu": args.reads, "read_len": READ_LEN, "k": k, "min_count": MIN_COUNT,
                        "chunk_mib": CHUNK_MIB, "chunks": len(offs) - 1, "mode": st["mode_name"], "contexts_per_gpu": nctx,
                        "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
