@@ -393,3 +393,77 @@ def test_count_device_unaligned_offsets():
             with native.Counter(k, native.ALPHABET_NT2) as ctx:
                 ctx.count_device(buf.data_ptr() + off, len(payload), 1)
                 assert ctx.to_dict() == want, (k, off)
+
+
+def _random_fasta(rng, alphabet, n_records, max_len, quirks):
+    out = []
+    for i in range(n_records):
+        n = int(rng.integers(0, max_len))
+        seq = bytes(alphabet[rng.integers(0, len(alphabet), n)])
+        width = int(rng.integers(1, 120))
+        lines = [seq[j:j + width] for j in range(0, len(seq), width)] or [b""]
+        nl = b"\r\n" if quirks and rng.random() < 0.2 else (b"\r" if quirks and rng.random() < 0.1 else b"\n")
+        hdr = b">r%d some text > here" % i if rng.random() < 0.5 else b">r%d" % i
+        if quirks and rng.random() < 0.15:
+            hdr = b"  " + hdr
+        body = []
+        for ln in lines:
+            if quirks and rng.random() < 0.1:
+                ln = b" " + ln + b"\t"
+            if quirks and rng.random() < 0.05:
+                ln = ln[: len(ln) // 2] + b" " + ln[len(ln) // 2:]
+            if quirks and rng.random() < 0.1:
+                ln = ln + b"*"
+            body.append(ln)
+        out.append(hdr + nl + nl.join(body) + nl)
+        if quirks and rng.random() < 0.1:
+            out.append(nl)
+    text = b"".join(out)
+    if quirks and rng.random() < 0.3:
+        text = text.rstrip(b"\r\n")
+    if quirks and rng.random() < 0.2:
+        text = b"ACGTTGCA" + b"\n" + text
+    return text
+
+
+def test_fuzz_against_oracle():
+    """Random small FASTA texts (wrapped lines, CRLF / CR, blanks, stars, '>' inside headers, empty
+    records, lower case, IUPAC, proteins), random k, min_count and chunk size: GPU == oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(2026)
+    nt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    nt_odd = np.frombuffer(b"ACGTACGTACGTNnacgtRY", dtype=np.uint8)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYXBZ", dtype=np.uint8)
+    for trial in range(120):
+        kind = trial % 4
+        alphabet = [nt, nt_odd, aa, nt][kind]
+        quirks = kind != 0 or trial % 8 == 0
+        data = _random_fasta(rng, alphabet, int(rng.integers(1, 60)), int(rng.integers(1, 900)), quirks)
+        k = int(rng.choice([1, 2, 3, 5, 7, 8, 11, 12, 13, 17, 18, 21, 25, 31, 32, 33, 40, 63, 64, 65, 90]))
+        c = int(rng.choice([1, 1, 2, 3]))
+        alpha = native.ALPHABET_AA5 if kind == 2 else (native.ALPHABET_RAW if trial % 17 == 0 else native.ALPHABET_NT2)
+        size = int(rng.integers(200, 20000))
+        offs = chunk_offsets(data, size) if trial % 3 == 0 else [0, len(data)]
+        with native.Counter(k, alpha) as ctx:
+            for a, b in zip(offs[:-1], offs[1:]):
+                ctx.count_chunk(data[a:b], c)
+            got = ctx.to_dict()
+        want = cpu_ref.merge_counts(c_oracle.count_dict(data[a:b], k, c) for a, b in zip(offs[:-1], offs[1:]))
+        assert got == want, (trial, kind, k, c, len(data), len(offs))
+
+
+def test_long_lines_and_long_headers():
+    """A 3 Mbp record on ONE line, a 200 kB header, and 70 kB of text in front of the first header:
+    lines far longer than a parser wave (4 KiB) or workgroup."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    big = lut[rng.integers(0, 4, 3_000_000)].tobytes()
+    pre = lut[rng.integers(0, 4, 70_000)].tobytes()
+    data = pre + b"\n>" + b"h" * 200_000 + b"\n" + big + b"\n>tail\n" + big[:5000] + b"\n"
+    for k in (21, 31, 63):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, 1)
+            kmers, counts = ctx.export()
+        okm, ocn = c_oracle.count(data, k, 1)
+        assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
