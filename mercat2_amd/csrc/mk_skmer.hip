@@ -50,7 +50,6 @@ __device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {
   h ^= h >> 11;
   h = (h * 0x1B873593u) & SK_MASK;
   h ^= h >> 13;
-  h = (h * 0x0019660Du) & SK_MASK;
   return h;
 }
 // 11-mer under which a window is filed: itself, or min(itself, reverse complement) in canonical mode.

@@ -43,7 +43,6 @@ __device__ __forceinline__ unsigned sk2_order_hash(unsigned mm) {
   h ^= h >> 11;
   h = (h * 0x1B873593u) & SK_MASK;
   h ^= h >> 13;
-  h = (h * 0x0019660Du) & SK_MASK;
   return h;
 }
 __device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
