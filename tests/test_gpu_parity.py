@@ -467,3 +467,38 @@ def test_long_lines_and_long_headers():
             kmers, counts = ctx.export()
         okm, ocn = c_oracle.count(data, k, 1)
         assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), k
+
+
+def test_full_size_properties_config3():
+    """BASELINE config 3 size (S2: 10 M x 150 bp from a 10 Mbp genome, k=31), size-independent
+    properties: (a) unchunked at c=1 the counts sum to the number of windows and the rows are
+    strictly ascending; (b) the 16 reference chunks at c=1 give the identical table (linearity of
+    the per-chunk merge); (c) at c=10 every chunked row also exists at c=1 with a count no larger;
+    (d) two contexts + device-side merge == one context."""
+    k = 31
+    data = native.synth_reads(10_000_000, 3, 10_000_000, 150, 4)
+    offs = chunk_offsets(data, 100 * 1024 * 1024)
+    assert len(offs) == 17
+    view = memoryview(data)
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(view, 1)  # one 1.6 GB chunk: buckets far larger than the LDS table -> sub-range splitting
+        km1, cn1 = ctx.export()
+        st = ctx.stats()
+    assert int(cn1.sum()) == 10_000_000 * (150 - k + 1) == st["windows"]
+    keys1 = km1.view("S%d" % k).reshape(-1)
+    assert np.all(keys1[:-1] < keys1[1:])
+    with native.Counter(k, native.ALPHABET_NT2) as a, native.Counter(k, native.ALPHABET_NT2) as b:
+        for i, (lo, hi) in enumerate(zip(offs[:-1], offs[1:])):
+            (a if i % 2 == 0 else b).count_chunk(view[lo:hi], 1)
+        a.merge_from(b)
+        km2, cn2 = a.export()
+    assert np.array_equal(km1, km2) and np.array_equal(cn1, cn2)
+    del km2, cn2
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            ctx.count_chunk(view[lo:hi], 10)
+        km10, cn10 = ctx.export()
+    keys10 = km10.view("S%d" % k).reshape(-1)
+    pos = np.searchsorted(keys1, keys10)
+    assert np.all(pos < keys1.size) and np.array_equal(keys1[pos], keys10)
+    assert np.all(cn10 <= cn1[pos]) and np.all(cn10 >= 10) and 0 < keys10.size < keys1.size
