@@ -502,3 +502,37 @@ def test_full_size_properties_config3():
     pos = np.searchsorted(keys1, keys10)
     assert np.all(pos < keys1.size) and np.array_equal(keys1[pos], keys10)
     assert np.all(cn10 <= cn1[pos]) and np.all(cn10 >= 10) and 0 < keys10.size < keys1.size
+
+
+def test_many_contexts_and_threads():
+    """Contexts are independent: 6 of them counting different inputs from 6 host threads at once,
+    then 150 create/count/destroy cycles (no leak, no cross-talk)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle
+    jobs = []
+    for i, (k, alpha) in enumerate([(31, native.ALPHABET_NT2), (3, native.ALPHABET_NT2), (12, native.ALPHABET_NT2),
+                                    (63, native.ALPHABET_NT2), (5, native.ALPHABET_AA5), (21, native.ALPHABET_RAW)]):
+        data = native.synth_reads(20_000 + i, 80 + i, 4_000, 150, 90 + i).tobytes()
+        if alpha == native.ALPHABET_AA5:
+            data = read_input("edge_protein.faa") * 20
+        jobs.append((k, alpha, data))
+
+    def run(job):
+        k, alpha, data = job
+        with native.Counter(k, alpha) as ctx:
+            for _ in range(3):
+                ctx.reset()
+                ctx.count_chunk(data, 2)
+            return ctx.to_dict()
+
+    with ThreadPoolExecutor(6) as pool:
+        got = list(pool.map(run, jobs))
+    for (k, alpha, data), g in zip(jobs, got):
+        assert g == c_oracle.count_dict(data, k, 2), (k, alpha)
+    small = read_input("A.fasta")
+    want = cpu_ref.count_text(small, 21, 1)
+    for i in range(150):
+        with native.Counter(21, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(small, 1)
+            if i % 50 == 0:
+                assert ctx.to_dict() == want
