@@ -97,6 +97,33 @@ int mk_chunk_end(mk_ctx* ctx, uint64_t min_count);
  * d_text must stay valid until the call returns. */
 int mk_count_device(mk_ctx* ctx, const uint8_t* d_text, size_t n, uint64_t min_count);
 
+/* ---- one file of a sample, from disk: chunk_files + a countKmers task per chunk + the dict sum
+ *      (bin/mercat2.py:86-106, 112-127), with the file reading of find_kmers
+ *      (lib/mercat2_kmers.py:47-50) and no chunk files ------------------------------------ */
+typedef struct mk_file_stats_t {
+  uint64_t disk_bytes; /* size of the file on disk                                           */
+  uint64_t text_bytes; /* (inflated) bytes read and fed                                      */
+  uint64_t chunks;     /* chunks counted (1 when the file was not chunked)                   */
+  int32_t gz;          /* 1: the file was inflated (last suffix ".gz")                        */
+  int32_t chunked;     /* 1: disk_bytes >= chunk_bytes, the Chunker rule was applied         */
+  int32_t members;     /* gzip members seen                                                  */
+  int32_t threads;     /* reader threads used                                                */
+  int32_t contexts;    /* contexts that counted chunks                                       */
+  int32_t pad_;
+  double s_wait_io;    /* seconds the dispatching thread waited for file blocks              */
+  double s_wait_gpu;   /* seconds it waited for a context to finish its previous chunk       */
+  double s_total;      /* wall seconds of the call                                           */
+} mk_file_stats_t;
+/* Reads `path` (gzip iff its name ends in ".gz", as the reference decides), splits it as
+ * Chunker(path, dest, chunk_bytes, '>') would iff its on-disk size is >= chunk_bytes > 0
+ * (chunk_bytes == 0: never), counts every chunk with its own min_count filter and adds the
+ * survivors to the running table of ctxs[0].  With nctx > 1 (same device, alphabet, k) the chunks
+ * are dealt to the contexts in turn and counted concurrently with the reading; the other
+ * contexts' tables are added into ctxs[0] and reset before the call returns.  threads = reader
+ * threads for plain files (<= 0: pick); a gzip stream is inflated by one thread.  st may be NULL. */
+int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, uint64_t chunk_bytes, uint64_t min_count,
+                  int threads, mk_file_stats_t* st);
+
 /* ---- result of the sample: sorted(kmers.items()) (bin/mercat2.py:130-133) --------------- */
 int mk_export_size(mk_ctx* ctx, size_t* rows);
 /* kmers: rows*k ASCII bytes (no terminators), counts: rows values; both caller-allocated.
@@ -133,6 +160,11 @@ int mk_reset_stats(mk_ctx* ctx);
  * chunksize.  cuts[0..*ncuts) ascending; chunk i is [cuts[i-1], cuts[i]) with cuts[-1] = 0
  * and cuts[ncuts] = n.  Returns MK_ERR_RANGE (and the needed size in *ncuts) if cap is short. */
 int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, uint64_t* cuts, size_t cap, size_t* ncuts);
+/* The same cuts computed by the streaming scanner mk_count_file uses, with the text handed over
+ * `block` bytes at a time (a self-check for tests: MK_ERR_STATE if the scanner lost, repeated or
+ * misplaced a byte). */
+int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts, size_t cap,
+                   size_t* ncuts);
 /* Deterministic synthetic reads: genome of `genome_len` iid ACGT from
  * splitmix64(genome_seed); `reads` reads of `read_len` from uniform starts, reverse-complemented
  * on a coin flip, per-base substitution with probability sub_ppm/1e6, all from

@@ -179,6 +179,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
                      &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->ingest_ring) (void)hipHostFree(c->ingest_ring);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -240,6 +241,23 @@ static int feed(mk_ctx* c, const uint8_t* p, size_t n, hipMemcpyKind kind) {
   if (kind == hipMemcpyHostToDevice) MK_HIP(hipStreamSynchronize(c->stream));  // caller may reuse its buffer
   c->raw_len += n;
   return MK_OK;
+}
+
+int mk_feed_host_async(mk_ctx* c, const uint8_t* p, size_t n, bool wait) {
+  if (!c || !c->in_chunk) return MK_ERR_STATE;
+  if (n == 0) return MK_OK;
+  MK_HIP(hipSetDevice(c->device));
+  int rc = mk_buf_reserve(c, c->raw, c->raw_len + n + 64, true);
+  if (rc) return rc;
+  MK_HIP(hipMemcpyAsync((uint8_t*)c->raw.p + c->raw_len, p, n, hipMemcpyHostToDevice, c->stream));
+  if (wait) MK_HIP(hipStreamSynchronize(c->stream));
+  c->raw_len += n;
+  return MK_OK;
+}
+
+int mk_reserve_raw(mk_ctx* c, size_t bytes) {
+  MK_HIP(hipSetDevice(c->device));
+  return mk_buf_reserve(c, c->raw, bytes, true);
 }
 
 extern "C" int mk_chunk_feed(mk_ctx* c, const uint8_t* text, size_t n) { return feed(c, text, n, hipMemcpyHostToDevice); }

@@ -81,6 +81,10 @@ struct MkDevBuf {
 // Simple growable device buffer helpers (implemented in mk_api.cpp)
 struct mk_ctx;
 int mk_buf_reserve(mk_ctx* c, MkDevBuf& b, size_t bytes, bool keep = false);
+// mk_api.hip, for mk_ingest.hip: append host bytes to the open chunk without waiting for the copy
+// (the source must stay untouched until the context's stream has passed it) unless wait is set
+int mk_feed_host_async(mk_ctx* c, const uint8_t* p, size_t n, bool wait);
+int mk_reserve_raw(mk_ctx* c, size_t bytes);
 
 struct MkEventPair {
   hipEvent_t a, b;
@@ -141,6 +145,10 @@ struct mk_ctx {
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
+
+  // pinned block ring of mk_count_file (mk_ingest.hip), kept between files
+  void* ingest_ring = nullptr;
+  size_t ingest_ring_bytes = 0;
 
   // stats
   mk_stats_t st{};

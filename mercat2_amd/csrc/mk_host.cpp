@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <vector>
 #include "../../include/mercat_hip.h"
+#include "mk_cutscan.h"
 
 // ---------------------------------------------------------------------------- virtual Chunker
 // Restates Chunker.stream_delim (lib/mercat2_Chunker.py:39-59) without writing chunk files:
@@ -45,6 +46,45 @@ extern "C" int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, 
   }
   *ncuts = found;
   return (found > cap && cuts) ? MK_ERR_RANGE : MK_OK;
+}
+
+// The same rule through the streaming scanner the file reader uses (mk_cutscan.h), fed `block`
+// bytes at a time.  Besides the cuts it checks that the scanner hands every byte on exactly
+// once, in order, and that each cut falls where the bytes fed so far end.
+namespace {
+struct RecordingSink : MkCutSink {
+  const uint8_t* text;
+  size_t fed = 0;
+  bool ok = true;
+  std::vector<uint64_t> cuts;
+  int feed(const uint8_t* p, size_t n) override {
+    if (memcmp(p, text + fed, n) != 0) ok = false;
+    fed += n;
+    return 0;
+  }
+  int cut(uint64_t abs) override {
+    if (abs != fed) ok = false;
+    cuts.push_back(abs);
+    return 0;
+  }
+};
+}  // namespace
+
+extern "C" int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts,
+                              size_t cap, size_t* ncuts) {
+  if (!ncuts || (n && !text) || block == 0) return MK_ERR_ARG;
+  RecordingSink sink;
+  sink.text = text;
+  MkCutScanner scan(chunksize, &sink);
+  for (size_t off = 0; off < n; off += block) {
+    const size_t m = n - off < block ? n - off : block;
+    scan.block(text + off, m, memchr(text + off, '\r', m) != nullptr);
+  }
+  scan.finish();
+  if (!sink.ok || sink.fed != n) return MK_ERR_STATE;
+  *ncuts = sink.cuts.size();
+  for (size_t i = 0; i < sink.cuts.size() && i < cap && cuts; ++i) cuts[i] = sink.cuts[i];
+  return (sink.cuts.size() > cap && cuts) ? MK_ERR_RANGE : MK_OK;
 }
 
 // ------------------------------------------------------------------------- synthetic reads

@@ -1,0 +1,443 @@
+// mk_ingest.hip -- native ingest: one FASTA file (plain or gzip) -> chunks -> contexts.
+//
+// Replaces, for one sample file, the reference's chunk_files + one countKmers task per chunk +
+// the dict sum (bin/mercat2.py:86-106, 112-127) and the file reading of find_kmers
+// (lib/mercat2_kmers.py:47-50) without writing chunk files: reader threads fill a ring of pinned
+// host blocks (pread for plain files, zlib inflate for '.gz'), the calling thread runs the
+// streaming Chunker rule over the blocks (mk_cutscan.h) and copies each byte range straight into
+// the raw buffer of the context that owns the current chunk (hipMemcpyAsync on that context's
+// stream), and one worker thread per context runs mk_chunk_end while the next chunk is being read.
+// Host code only; all GPU work is behind the per-context calls of mk_api.hip.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+
+#include "mk_common.h"
+#include "mk_cutscan.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+static double seconds_since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// ---------------------------------------------------------------------------------- the ring
+struct Ring {
+  size_t block = 0;
+  int slots = 0;
+  uint8_t* mem = nullptr;  // pinned, slots * block bytes
+  std::vector<size_t> len;
+  std::vector<char> has_cr;
+  std::vector<uint64_t> holds;  // slot -> 1 + index of the block it holds (0 = none)
+  std::mutex mu;
+  std::condition_variable cv;
+  uint64_t released = 0;            // blocks [0, released) may be overwritten
+  uint64_t total = UINT64_MAX;      // number of blocks of the text, once known
+  std::atomic<uint64_t> next{0};    // next block index a reader takes
+  bool abort = false;
+  int rc = MK_OK;
+  std::string err;
+
+  uint8_t* at(uint64_t i) const { return mem + (size_t)(i % (uint64_t)slots) * block; }
+  void fail(int code, const std::string& what) {
+    std::lock_guard<std::mutex> g(mu);
+    if (rc == MK_OK) { rc = code; err = what; }
+    abort = true;
+    cv.notify_all();
+  }
+  // reader side: wait until block i may be written; false = give up
+  bool wait_writable(uint64_t i) {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return abort || i < released + (uint64_t)slots; });
+    return !abort;
+  }
+  void publish(uint64_t i, size_t n, bool cr) {
+    std::lock_guard<std::mutex> g(mu);
+    const int s = (int)(i % (uint64_t)slots);
+    len[s] = n;
+    has_cr[s] = cr;
+    holds[s] = i + 1;
+    cv.notify_all();
+  }
+  void set_total(uint64_t t) {
+    std::lock_guard<std::mutex> g(mu);
+    total = t;
+    cv.notify_all();
+  }
+  // consumer side: 1 = block i is ready, 0 = the text ended before block i, <0 = error
+  int wait_ready(uint64_t i) {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return abort || holds[i % (uint64_t)slots] == i + 1 || i >= total; });
+    if (abort) return rc ? rc : MK_ERR_STATE;
+    return holds[i % (uint64_t)slots] == i + 1 ? 1 : 0;
+  }
+  void release_upto(uint64_t r) {
+    std::lock_guard<std::mutex> g(mu);
+    if (r > released) released = r;
+    cv.notify_all();
+  }
+};
+
+static bool read_fully(int fd, uint8_t* dst, size_t want, off_t off, size_t* got) {
+  size_t done = 0;
+  while (done < want) {
+    const ssize_t r = pread(fd, dst + done, want - done, off + (off_t)done);
+    if (r < 0) return false;
+    if (r == 0) break;
+    done += (size_t)r;
+  }
+  *got = done;
+  return true;
+}
+
+// plain file: block i is bytes [i*block, (i+1)*block) of the file; any thread may read any block
+static void plain_reader(Ring* R, int fd, uint64_t nblocks, const std::string* path) {
+  for (;;) {
+    const uint64_t i = R->next.fetch_add(1);
+    if (i >= nblocks) return;
+    if (!R->wait_writable(i)) return;
+    size_t got = 0;
+    if (!read_fully(fd, R->at(i), R->block, (off_t)(i * R->block), &got)) {
+      R->fail(MK_ERR_IO, "read " + *path + ": " + strerror(errno));
+      return;
+    }
+    R->publish(i, got, got && memchr(R->at(i), '\r', got) != nullptr);
+  }
+}
+
+// gzip: one thread inflates member after member (as Python's gzip module does) into successive blocks
+static void gz_reader(Ring* R, int fd, const std::string* path, int* members_out) {
+  std::vector<uint8_t> in(1u << 20);
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, 15 + 16) != Z_OK) { R->fail(MK_ERR_NOMEM, "inflateInit2 failed"); return; }
+  uint64_t i = 0;
+  size_t fill = 0;       // bytes in block i so far
+  bool have_block = false;
+  bool in_member = false, eof = false;
+  int members = 0;
+  off_t off = 0;
+  auto flush_block = [&]() {
+    R->publish(i, fill, fill && memchr(R->at(i), '\r', fill) != nullptr);
+    ++i;
+    fill = 0;
+    have_block = false;
+  };
+  for (;;) {
+    if (zs.avail_in == 0 && !eof) {
+      const ssize_t r = pread(fd, in.data(), in.size(), off);
+      if (r < 0) { R->fail(MK_ERR_IO, "read " + *path + ": " + strerror(errno)); break; }
+      if (r == 0) eof = true;
+      off += r;
+      zs.next_in = in.data();
+      zs.avail_in = (uInt)r;
+    }
+    if (zs.avail_in == 0 && eof) {
+      if (in_member) { R->fail(MK_ERR_IO, *path + ": gzip stream ends inside a member"); }
+      break;
+    }
+    if (!in_member) {
+      // between members: zero padding is skipped (as gzip.py does); anything else must be a member
+      while (zs.avail_in && *zs.next_in == 0) { ++zs.next_in; --zs.avail_in; }
+      if (zs.avail_in == 0) continue;
+      in_member = true;
+    }
+    if (!have_block) {
+      if (!R->wait_writable(i)) break;
+      have_block = true;
+    }
+    zs.next_out = R->at(i) + fill;
+    zs.avail_out = (uInt)(R->block - fill);
+    const int z = inflate(&zs, Z_NO_FLUSH);
+    fill = R->block - zs.avail_out;
+    if (z == Z_STREAM_END) {
+      ++members;
+      in_member = false;
+      inflateReset(&zs);
+    } else if (z != Z_OK && z != Z_BUF_ERROR) {
+      R->fail(MK_ERR_IO, *path + ": not a gzip file or corrupt (" + std::string(zs.msg ? zs.msg : "inflate error") + ")");
+      break;
+    } else if (z == Z_BUF_ERROR && zs.avail_in == 0 && eof) {
+      R->fail(MK_ERR_IO, *path + ": gzip stream is truncated");
+      break;
+    }
+    if (fill == R->block) flush_block();
+  }
+  if (have_block && fill) flush_block();
+  inflateEnd(&zs);
+  *members_out = members;
+  R->set_total(i);
+}
+
+// ------------------------------------------------------------------------- context workers
+struct Lane {  // one context, its worker thread and the hand-over between dispatcher and worker
+  mk_ctx* c = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  enum { IDLE, FEEDING, ENDING, QUIT } state = IDLE;
+  uint64_t min_count = 0;
+  int rc = MK_OK;
+  std::thread th;
+};
+
+static void lane_worker(Lane* L) {
+  for (;;) {
+    std::unique_lock<std::mutex> g(L->mu);
+    L->cv.wait(g, [&] { return L->state == Lane::ENDING || L->state == Lane::QUIT; });
+    if (L->state == Lane::QUIT) return;
+    g.unlock();
+    const int rc = mk_chunk_end(L->c, L->min_count);
+    g.lock();
+    if (rc && !L->rc) L->rc = rc;
+    L->state = Lane::IDLE;
+    L->cv.notify_all();
+  }
+}
+
+struct Dispatcher : MkCutSink {
+  std::vector<Lane>* lanes = nullptr;
+  Ring* ring = nullptr;
+  int cur = -1;          // lane that owns the open chunk (-1: none open)
+  int next_lane = 0;
+  uint64_t chunks = 0;
+  uint64_t min_count = 0;
+  size_t reserve = 0;    // raw-buffer bytes to set aside when a chunk is opened
+  double s_wait_gpu = 0;
+  std::vector<int> touched;  // lanes that received bytes of the block being processed
+  int rc_lane = -1;
+
+  int open_chunk() {
+    Lane& L = (*lanes)[next_lane];
+    {
+      const auto t0 = Clock::now();
+      std::unique_lock<std::mutex> g(L.mu);
+      L.cv.wait(g, [&] { return L.state == Lane::IDLE; });
+      s_wait_gpu += seconds_since(t0);
+      if (L.rc) { rc_lane = next_lane; return L.rc; }
+      L.state = Lane::FEEDING;
+    }
+    cur = next_lane;
+    next_lane = (next_lane + 1) % (int)lanes->size();
+    int rc = mk_chunk_begin(L.c);
+    if (!rc && reserve) rc = mk_reserve_raw(L.c, reserve);
+    if (rc) rc_lane = cur;
+    return rc;
+  }
+  int close_chunk() {
+    if (cur < 0) return MK_OK;
+    Lane& L = (*lanes)[cur];
+    {
+      std::lock_guard<std::mutex> g(L.mu);
+      L.min_count = min_count;
+      L.state = Lane::ENDING;
+      L.cv.notify_all();
+    }
+    cur = -1;
+    ++chunks;
+    return MK_OK;
+  }
+  int feed(const uint8_t* p, size_t n) override {
+    if (n == 0) return MK_OK;
+    int rc;
+    if (cur < 0 && (rc = open_chunk())) return rc;
+    mk_ctx* c = (*lanes)[cur].c;
+    const bool pinned = p >= ring->mem && p < ring->mem + (size_t)ring->slots * ring->block;
+    if ((rc = mk_feed_host_async(c, p, n, /*wait=*/!pinned))) { rc_lane = cur; return rc; }
+    if (pinned && (touched.empty() || touched.back() != cur)) touched.push_back(cur);
+    return MK_OK;
+  }
+  int cut(uint64_t) override { return close_chunk(); }
+};
+
+}  // namespace
+
+extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, uint64_t chunk_bytes, uint64_t min_count,
+                             int threads, mk_file_stats_t* st) {
+  if (!ctxs || nctx < 1 || !ctxs[0]) return MK_ERR_ARG;
+  mk_ctx* c0 = ctxs[0];
+  if (!path) { c0->err = "mk_count_file: path is NULL"; return MK_ERR_ARG; }
+  for (int j = 0; j < nctx; ++j) {
+    if (!ctxs[j]) { c0->err = "mk_count_file: a context is NULL"; return MK_ERR_ARG; }
+    if (ctxs[j]->in_chunk) { c0->err = "mk_count_file: a chunk is open"; return MK_ERR_STATE; }
+    if (ctxs[j]->device != c0->device || ctxs[j]->alphabet != c0->alphabet || ctxs[j]->k != c0->k ||
+        ctxs[j]->canonical != c0->canonical) {
+      c0->err = "mk_count_file: contexts differ in device, alphabet, k or canonical mode";
+      return MK_ERR_ARG;
+    }
+    for (int i = 0; i < j; ++i)
+      if (ctxs[i] == ctxs[j]) { c0->err = "mk_count_file: the same context twice"; return MK_ERR_ARG; }
+  }
+  const auto t_begin = Clock::now();
+  const std::string spath(path);
+  const int fd = open(path, O_RDONLY | O_CLOEXEC);
+  if (fd < 0) { c0->err = "open " + spath + ": " + strerror(errno); return MK_ERR_IO; }
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) { c0->err = "stat " + spath + ": " + strerror(errno); close(fd); return MK_ERR_IO; }
+  const uint64_t disk = (uint64_t)sb.st_size;
+  // '.gz' iff the last suffix says so: the reference's test (lib/mercat2_kmers.py:47, lib/mercat2_Chunker.py:42)
+  const bool gz = spath.size() >= 3 && spath.compare(spath.size() - 3, 3, ".gz") == 0;
+  // chunk iff the ON-DISK size reaches the chunk size (bin/mercat2.py:101)
+  const bool chunked = chunk_bytes > 0 && disk >= chunk_bytes;
+  const int lanes_n = chunked ? nctx : 1;
+
+  if (threads <= 0) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  if (gz) threads = 1;
+  if (hipSetDevice(c0->device) != hipSuccess) { c0->err = "hipSetDevice failed"; close(fd); return MK_ERR_HIP; }
+
+  Ring R;
+  {
+    const char* e = getenv("MK_INGEST_BLOCK");  // (tests shrink the blocks to put every boundary case in reach)
+    R.block = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)4 << 20);
+    R.slots = 2 * threads + 4;
+    const size_t bytes = (size_t)R.slots * R.block;
+    if (c0->ingest_ring_bytes < bytes) {
+      if (c0->ingest_ring) (void)hipHostFree(c0->ingest_ring);
+      c0->ingest_ring = nullptr;
+      c0->ingest_ring_bytes = 0;
+      const hipError_t he = hipHostMalloc(&c0->ingest_ring, bytes, hipHostMallocDefault);
+      if (he != hipSuccess) {
+        c0->err = "hipHostMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(he);
+        close(fd);
+        return MK_ERR_NOMEM;
+      }
+      c0->ingest_ring_bytes = bytes;
+    }
+    R.mem = (uint8_t*)c0->ingest_ring;
+    R.len.assign(R.slots, 0);
+    R.has_cr.assign(R.slots, 0);
+    R.holds.assign(R.slots, 0);
+  }
+
+  // raw-buffer size to set aside per chunk, so that feeding never has to grow it mid-chunk
+  size_t reserve = 0;
+  if (chunked) {
+    reserve = (size_t)chunk_bytes + ((size_t)8 << 20);
+  } else if (!gz) {
+    reserve = (size_t)disk + 64;
+  } else if (disk >= 18) {
+    uint8_t tail[4];
+    if (pread(fd, tail, 4, (off_t)disk - 4) == 4) {  // ISIZE of the last member: a hint, nothing more
+      const uint64_t isize = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24);
+      reserve = (size_t)std::max<uint64_t>(isize, disk) + 64;
+    }
+  }
+
+  std::vector<Lane> lanes(lanes_n);
+  for (int j = 0; j < lanes_n; ++j) {
+    lanes[j].c = ctxs[j];
+    lanes[j].th = std::thread(lane_worker, &lanes[j]);
+  }
+  std::vector<hipEvent_t> events((size_t)R.slots * lanes_n, nullptr);
+  std::vector<char> ev_set((size_t)R.slots * lanes_n, 0);
+  int rc = MK_OK;
+  for (auto& e : events)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = MK_ERR_HIP;
+
+  int members = 0;
+  std::vector<std::thread> readers;
+  uint64_t nblocks = 0;
+  if (rc == MK_OK) {
+    if (gz) {
+      readers.emplace_back(gz_reader, &R, fd, &spath, &members);
+    } else {
+      nblocks = (disk + R.block - 1) / R.block;
+      R.total = nblocks;
+      for (int t = 0; t < threads && (uint64_t)t < std::max<uint64_t>(nblocks, 1); ++t)
+        readers.emplace_back(plain_reader, &R, fd, nblocks, &spath);
+    }
+  }
+
+  Dispatcher D;
+  D.lanes = &lanes;
+  D.ring = &R;
+  D.min_count = min_count;
+  D.reserve = reserve;
+  MkCutScanner scan(chunked ? chunk_bytes : UINT64_MAX, &D);
+  uint64_t text_bytes = 0;
+  double s_wait_io = 0;
+  const uint64_t lag = (uint64_t)R.slots / 2;
+  auto retire = [&](uint64_t i) {  // wait for the copies out of block i, then let the readers have its slot
+    for (int j = 0; j < lanes_n; ++j) {
+      const size_t e = (size_t)(i % (uint64_t)R.slots) * lanes_n + j;
+      if (ev_set[e]) { (void)hipEventSynchronize(events[e]); ev_set[e] = 0; }
+    }
+    R.release_upto(i + 1);
+  };
+  uint64_t i = 0;
+  for (; rc == MK_OK; ++i) {
+    const auto t0 = Clock::now();
+    const int ready = R.wait_ready(i);
+    s_wait_io += seconds_since(t0);
+    if (ready < 0) { rc = ready; break; }
+    if (ready == 0) break;
+    const int s = (int)(i % (uint64_t)R.slots);
+    const size_t n = R.len[s];
+    D.touched.clear();
+    if ((rc = scan.block(R.at(i), n, R.has_cr[s] != 0)) != MK_OK) break;
+    text_bytes += n;
+    for (int j : D.touched) {
+      const size_t e = (size_t)s * lanes_n + j;
+      if (hipEventRecord(events[e], lanes[j].c->stream) != hipSuccess) { rc = MK_ERR_HIP; break; }
+      ev_set[e] = 1;
+    }
+    if (i >= lag) retire(i - lag);
+  }
+  if (rc == MK_OK) rc = scan.finish();
+  if (rc == MK_OK && D.cur < 0 && D.chunks == 0) rc = D.open_chunk();  // an empty file is one empty chunk
+  if (rc == MK_OK) rc = D.close_chunk();
+  if (rc != MK_OK) R.fail(rc, "");
+  // drain: copies first (the readers may be waiting for slots), then the readers, then the workers
+  for (uint64_t r = (i > lag ? i - lag : 0); r < i; ++r) retire(r);
+  for (auto& t : readers) t.join();
+  if (rc == MK_OK && R.rc != MK_OK) rc = R.rc;
+  for (int j = 0; j < lanes_n; ++j) {
+    Lane& L = lanes[j];
+    {
+      std::unique_lock<std::mutex> g(L.mu);
+      if (L.state == Lane::FEEDING) {  // a chunk left open by an error: drop it
+        L.c->in_chunk = false;
+        L.c->raw_len = 0;
+        L.state = Lane::IDLE;
+      }
+      L.cv.wait(g, [&] { return L.state == Lane::IDLE; });
+      L.state = Lane::QUIT;
+      L.cv.notify_all();
+    }
+    L.th.join();
+    if (rc == MK_OK && L.rc != MK_OK) { rc = L.rc; D.rc_lane = j; }
+  }
+  for (auto& e : events)
+    if (e) (void)hipEventDestroy(e);
+  close(fd);
+  if (rc != MK_OK) {
+    if (!R.err.empty()) c0->err = R.err;
+    else if (D.rc_lane > 0) c0->err = ctxs[D.rc_lane]->err;
+    return rc;
+  }
+  // the sample's table ends up in ctxs[0]
+  for (int j = 1; j < lanes_n; ++j) {
+    if ((rc = mk_merge_from(c0, ctxs[j])) != MK_OK) return rc;
+    if ((rc = mk_reset(ctxs[j])) != MK_OK) { c0->err = ctxs[j]->err; return rc; }
+  }
+  if (st) {
+    memset(st, 0, sizeof *st);
+    st->disk_bytes = disk;
+    st->text_bytes = text_bytes;
+    st->chunks = D.chunks;
+    st->gz = gz ? 1 : 0;
+    st->chunked = chunked ? 1 : 0;
+    st->members = members;
+    st->threads = threads;
+    st->contexts = lanes_n;
+    st->s_wait_io = s_wait_io;
+    st->s_wait_gpu = D.s_wait_gpu;
+    st->s_total = seconds_since(t_begin);
+  }
+  return MK_OK;
+}

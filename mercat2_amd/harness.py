@@ -15,8 +15,8 @@ from pathlib import Path
 from typing import List, Optional, Sequence, Tuple
 
 from . import native
-from .chunker import Chunker, chunk_offsets
-from .kmers import find_kmers, guess_alphabet, map_fasta, read_fasta_bytes
+from .chunker import Chunker
+from .kmers import find_kmers, guess_alphabet, read_fasta_bytes, read_head
 
 
 def chunk_files(name: str, filename: str, chunk_size: int, outpath: str) -> Tuple[str, List[str]]:
@@ -57,35 +57,26 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
-               *, device: int = 0, streams: int = 2, canonical: bool = False) -> Tuple[str, Optional[os.PathLike]]:
-    """chunk_files + run_mercat2 in one step with no chunk files: the file is read (inflated)
-    once, the reference's cut points are computed over the bytes, and each byte range is
-    counted as one chunk (filtered on its own).  Same TSV as the two-step path.
+               *, device: int = 0, streams: int = 2, canonical: bool = False, threads: int = 0,
+               stats: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
+    """chunk_files + run_mercat2 in one step with no chunk files (mk_count_file): native reader
+    threads read (inflate) the file once into pinned blocks, the reference's cut rule is applied to
+    the stream, and each chunk is copied to the GPU and counted (filtered on its own) while the next
+    one is being read.  Same TSV as the two-step path.
 
-    ``streams`` contexts (HIP streams) count different chunks concurrently -- the host-to-device
-    copy and parse of one chunk overlap the LDS-bound counting of another -- and are summed on
-    the device at the end (mk_merge_from).  ``canonical`` is the opt-in extension of
-    mk_set_canonical (not reference behaviour)."""
-    from concurrent.futures import ThreadPoolExecutor
-    data = map_fasta(file)  # plain files: memory-mapped, no host copy
-    chunked = chunk_mib > 0 and os.stat(file).st_size >= chunk_mib * 1024 * 1024
-    offs = chunk_offsets(data, chunk_mib * 1024 * 1024) if chunked else [0, len(data)]
-    chunks = list(zip(offs[:-1], offs[1:]))
-    view = memoryview(data)
-    alphabet = guess_alphabet(file, data)
-    n = max(1, min(int(streams), len(chunks)))
+    ``streams`` contexts (HIP streams) take the chunks in turn and count concurrently; they are
+    summed on the device at the end.  ``threads`` = reader threads for plain files (0: pick).
+    ``canonical`` is the opt-in extension of mk_set_canonical (not reference behaviour).  If a dict
+    is passed as ``stats`` it receives the mk_file_stats_t fields of the read."""
+    chunk_bytes = max(0, int(chunk_mib)) * 1024 * 1024
+    chunked = chunk_bytes > 0 and os.stat(file).st_size >= chunk_bytes
+    alphabet = guess_alphabet(file, read_head(file))
+    n = max(1, int(streams)) if chunked else 1
     ctxs = [native.Counter(kmer, alphabet, device, canonical=canonical and alphabet == native.ALPHABET_NT2) for _ in range(n)]
     try:
-        def share(i):
-            for a, b in chunks[i::n]:
-                ctxs[i].count_chunk(view[a:b], min_count)
-        if n == 1:
-            share(0)
-        else:
-            with ThreadPoolExecutor(n) as pool:  # ctypes releases the GIL inside the ABI calls
-                list(pool.map(share, range(n)))
-            for other in ctxs[1:]:
-                ctxs[0].merge_from(other)
+        st = native.count_file(ctxs, file, chunk_bytes, min_count, threads)
+        if stats is not None:
+            stats.update(st)
         return _finish(ctxs[0], basename, out_file)
     finally:
         for c in ctxs:

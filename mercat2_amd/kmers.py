@@ -25,6 +25,13 @@ def read_fasta_bytes(file: Union[str, Path]) -> bytes:
     return p.read_bytes()
 
 
+def read_head(file: Union[str, Path], n: int = 4096) -> bytes:
+    """The first ``n`` (decompressed) bytes of a FASTA, to pick the alphabet from."""
+    p = Path(file)
+    with (gzip.open(p, "rb") if p.suffix == ".gz" else open(p, "rb")) as fh:
+        return fh.read(n)
+
+
 def map_fasta(file: Union[str, Path]):
     """Buffer over the (decompressed) bytes of a FASTA without an extra copy where possible:
     plain files are memory-mapped (the engine copies straight from the page cache to the GPU),
@@ -80,9 +87,8 @@ def find_kmers(file: Path, kmer: int, min_count: int, *, device: int = 0, alphab
     Returns:
         dict: {k-mer string: count} for every k-mer with count >= min_count in this file.
     """
-    data = read_fasta_bytes(file)
     if alphabet is None:
-        alphabet = guess_alphabet(file, data)
+        alphabet = guess_alphabet(file, read_head(file))
     with native.Counter(kmer, alphabet, device) as ctx:
-        ctx.count_chunk(data, min_count)
+        native.count_file([ctx], file, 0, min_count)  # the whole file is one chunk
         return ctx.to_dict()

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from pathlib import Path
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "mk_chunk_feed_device", "mk_chunk_end", "mk_count_device", "mk_export_size", "mk_export",
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
-    "mk_chunk_cuts", "mk_synth_reads", "mk_version",
+    "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
 ]
 
 
@@ -50,6 +50,16 @@ class Stats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class FileStats(C.Structure):
+    """mk_file_stats_t (include/mercat_hip.h)."""
+    _fields_ = ([(n, C.c_uint64) for n in ("disk_bytes", "text_bytes", "chunks")] +
+                [(n, C.c_int32) for n in ("gz", "chunked", "members", "threads", "contexts", "pad_")] +
+                [(n, C.c_double) for n in ("s_wait_io", "s_wait_gpu", "s_total")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
 
 
 _LIB: Optional[C.CDLL] = None
@@ -97,6 +107,9 @@ def lib() -> C.CDLL:
         "mk_synth_reads": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32,
                                      C.c_uint64, u8p, C.c_size_t, szp]),
         "mk_version": (C.c_char_p, []),
+        "mk_count_file": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int,
+                                    C.POINTER(FileStats)]),
+        "mk_stream_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -141,6 +154,37 @@ def chunk_cuts(text, chunksize: int) -> np.ndarray:
         if rc != -7:
             raise MercatHipError(rc, "mk_chunk_cuts")
         cap = need.value
+
+
+def stream_cuts(text, chunksize: int, block: int) -> np.ndarray:
+    """chunk_cuts through the streaming scanner of mk_count_file, the text handed over ``block`` bytes
+    at a time; raises if the scanner lost, repeated or misplaced a byte."""
+    L = lib()
+    addr, n, keep = _buf_ptr(text)
+    need = C.c_size_t(0)
+    cap = 64
+    while True:
+        cuts = np.empty(cap, dtype=np.uint64)
+        rc = L.mk_stream_cuts(addr, n, int(chunksize), int(block), cuts.ctypes.data, cap, C.byref(need))
+        if rc == MK_OK:
+            return cuts[: need.value].copy()
+        if rc != -7:
+            raise MercatHipError(rc, "mk_stream_cuts")
+        cap = need.value
+
+
+def count_file(ctxs: Sequence["Counter"], path, chunk_bytes: int, min_count: int, threads: int = 0) -> dict:
+    """mk_count_file: read (inflate) ``path``, apply the Chunker rule iff its on-disk size is >=
+    chunk_bytes > 0, count every chunk with its own min_count filter on the contexts in turn and leave
+    the sum in ctxs[0].  Returns the mk_file_stats_t fields."""
+    L = lib()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    st = FileStats()
+    rc = L.mk_count_file(arr, len(ctxs), os.fsencode(str(path)), int(chunk_bytes), int(min_count), int(threads),
+                         C.byref(st))
+    if rc:
+        ctxs[0]._check(rc)
+    return st.as_dict()
 
 
 def synth_reads(genome_len: int, genome_seed: int, reads: int, read_len: int, read_seed: int,

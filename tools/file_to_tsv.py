@@ -15,12 +15,23 @@ def main():
         f.write(memoryview(data))
     print("generated %s (%.2f GB) in %.1f s" % (path, data.nbytes / 1e9, time.perf_counter() - t0))
     del data
-    for streams in (1, 2):
-        for rep in range(2):
-            out = os.path.join(d, "S2_counts_%d.tsv" % streams)
-            t0 = time.perf_counter()
-            harness.run_sample("S2", path, out, k, 10, 100, streams=streams)
-            dt = time.perf_counter() - t0
-            print("streams=%d rep=%d file-to-TSV %.2f s = %.2f Gbases/s (tsv %.1f MB)" % (streams, rep, dt, reads * 150 / dt / 1e9, os.path.getsize(out) / 1e6))
+    gz = None
+    if "--gz" in sys.argv:
+        import subprocess
+        t0 = time.perf_counter()
+        subprocess.run(["gzip", "-1", "-k", path], check=True)
+        gz = path + ".gz"
+        print("gzip -1 -> %.2f GB in %.1f s" % (os.path.getsize(gz) / 1e9, time.perf_counter() - t0))
+    for f in [path] + ([gz] if gz else []):
+        for streams, threads in ((1, 0), (2, 0), (2, 2), (2, 16)):
+            for rep in range(2):
+                out = os.path.join(d, "S2_counts_%d.tsv" % streams)
+                st = {}
+                t0 = time.perf_counter()
+                harness.run_sample("S2", f, out, k, 10, 100, streams=streams, threads=threads, stats=st)
+                dt = time.perf_counter() - t0
+                print("%s streams=%d threads=%d rep=%d file-to-TSV %.3f s = %.2f Gbases/s (tsv %.1f MB) read+count %.3f s, wait io %.3f gpu %.3f, chunks %d"
+                      % (os.path.basename(f), streams, st["threads"], rep, dt, reads * 150 / dt / 1e9, os.path.getsize(out) / 1e6,
+                         st["s_total"], st["s_wait_io"], st["s_wait_gpu"], st["chunks"]))
 
 main()
