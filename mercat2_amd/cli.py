@@ -26,7 +26,8 @@ def parseargs(argv=None):
     p.add_argument("-i", required=False, default=list(), help="path to input file", nargs="+")
     p.add_argument("-f", type=str, required=False, help="path to folder containing input files")
     p.add_argument("-k", type=int, required=True, help="kmer length")
-    p.add_argument("-n", type=int, default=os.cpu_count() or 1, help="no of cores [auto detect] (accepted, unused)")
+    p.add_argument("-n", type=int, default=os.cpu_count() or 1,
+                   help="no of cores [auto detect]: samples read (inflated) and counted concurrently, at most 8")
     p.add_argument("-c", type=int, default=10, help="minimum kmer count [10]")
     p.add_argument("-s", type=int, default=100, required=False, help="Split into x MB files. [100]")
     p.add_argument("-o", type=str, default="mercat_results", required=False, help="Output folder")
@@ -87,9 +88,25 @@ def main(argv=None) -> int:
         tsv_dir = out / f"tsv_{kind}"
         tsv_dir.mkdir(parents=True, exist_ok=True)
         start = timeit.default_timer()
-        for base, f in samples[kind].items():
+        # Samples are independent (bin/mercat2.py:336-339).  A '.gz' sample is bound by its one inflating
+        # thread, so up to -n samples (at most 8) are in flight at once, each with its own contexts; the
+        # lines the reference prints per sample are kept and shown in sample order.
+        def one(item):
+            base, f = item
+            lines = []
             run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
-                       streams=args.streams, canonical=args.canonical)
+                       streams=args.streams, canonical=args.canonical, report=lines.append)
+            return lines
+        workers = max(1, min(int(args.n), 8, len(samples[kind])))
+        if workers == 1:
+            results = map(one, samples[kind].items())
+        else:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(workers)
+            results = pool.map(one, samples[kind].items())
+        for lines in results:
+            for line in lines:
+                print(line)
         print(f"Time to count {args.k}-mers: {round(timeit.default_timer() - start, 2)} seconds")
     return 0
 

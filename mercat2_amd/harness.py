@@ -34,12 +34,12 @@ def countKmers(file, kmer: int, min_count: int, device: int = 0):
     return find_kmers(Path(file), kmer, min_count, device=device)
 
 
-def _finish(ctx: native.Counter, basename: str, out_file) -> Tuple[str, Optional[os.PathLike]]:
+def _finish(ctx: native.Counter, basename: str, out_file, report=print) -> Tuple[str, Optional[os.PathLike]]:
     rows = ctx.write_tsv(out_file, basename)
     if rows:
-        print(f"Significant k-mers: {rows}")
+        report(f"Significant k-mers: {rows}")
         return basename, out_file
-    print("No significant k-mers found")
+    report("No significant k-mers found")
     return basename, None
 
 
@@ -58,7 +58,7 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
                *, device: int = 0, streams: int = 2, canonical: bool = False, threads: int = 0,
-               stats: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
+               stats: Optional[dict] = None, report=print) -> Tuple[str, Optional[os.PathLike]]:
     """chunk_files + run_mercat2 in one step with no chunk files (mk_count_file): native reader
     threads read (inflate) the file once into pinned blocks, the reference's cut rule is applied to
     the stream, and each chunk is copied to the GPU and counted (filtered on its own) while the next
@@ -67,7 +67,8 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
     ``streams`` contexts (HIP streams) take the chunks in turn and count concurrently; they are
     summed on the device at the end.  ``threads`` = reader threads for plain files (0: pick).
     ``canonical`` is the opt-in extension of mk_set_canonical (not reference behaviour).  If a dict
-    is passed as ``stats`` it receives the mk_file_stats_t fields of the read."""
+    is passed as ``stats`` it receives the mk_file_stats_t fields of the read.  ``report`` receives
+    the one line the reference prints per sample."""
     chunk_bytes = max(0, int(chunk_mib)) * 1024 * 1024
     chunked = chunk_bytes > 0 and os.stat(file).st_size >= chunk_bytes
     alphabet = guess_alphabet(file, read_head(file))
@@ -77,7 +78,7 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
         st = native.count_file(ctxs, file, chunk_bytes, min_count, threads)
         if stats is not None:
             stats.update(st)
-        return _finish(ctxs[0], basename, out_file)
+        return _finish(ctxs[0], basename, out_file, report)
     finally:
         for c in ctxs:
             c.close()

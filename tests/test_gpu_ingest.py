@@ -153,3 +153,31 @@ def test_run_sample_on_golden_protein_chunks(tmp_path):
     name, path = run_sample("DJ_pro", src, out, 3, 10, chunk_mib=1, streams=2, stats=stats)
     assert stats["chunks"] == nchunks == 3 and stats["contexts"] == 2
     assert out.read_text() == cpu_ref.tsv_text("DJ_pro", want)
+
+
+def test_cli_folder_of_samples_in_parallel(tmp_path, capsys):
+    """-f with several samples (.gz and plain, nucleotide and protein), counted concurrently (-n 4):
+    every TSV equals the oracle's and the per-sample lines come out in sample order."""
+    import shutil
+    from mercat2_amd import cli
+    folder = tmp_path / "in"
+    folder.mkdir()
+    names = ["RW1.fna.gz", "Test_R1.fna.gz", "A.fasta", "B.fasta", "RW1_pro.faa.gz", "edge_protein.faa", "edge_empty.fa"]
+    for n in names:
+        shutil.copy(GOLDEN / "inputs" / n, folder / n)
+    out = tmp_path / "res"
+    assert cli.main(["-f", str(folder), "-k", "4", "-c", "3", "-n", "4", "-o", str(out)]) == 0
+    printed = capsys.readouterr().out
+    nrows = []
+    for n in sorted(names):
+        kind, base = cli.classify(Path(n))
+        p = folder / n
+        data = gzip.open(p, "rb").read() if n.endswith(".gz") else p.read_bytes()
+        want = cpu_ref.count_text(data, 4, 3)
+        tsv = out / f"tsv_{kind}" / f"{base}_counts.tsv"
+        if want:
+            assert tsv.read_text() == cpu_ref.tsv_text(base, want), n
+        else:
+            assert not tsv.exists()
+    assert printed.count("Significant k-mers:") + printed.count("No significant k-mers found") == len(names)
+    assert printed.count("Time to count 4-mers:") == 2
