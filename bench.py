@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--read-seed", type=int, default=READ_SEED)
     ap.add_argument("--sub-ppm", type=int, default=0, help="per-base substitution rate, parts per million (S2e: 10000)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "2")),
+    ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "0")),
                     help="engine contexts (HIP streams) per GPU; chunks are dealt round-robin and counted "
                          "concurrently, the tables are merged on the device at the end of the step")
     args = ap.parse_args()
@@ -123,7 +123,7 @@ def main():
     windows_rank = args.reads * (READ_LEN - k + 1)
 
     from concurrent.futures import ThreadPoolExecutor
-    nctx = max(1, args.contexts)
+    nctx = args.contexts if args.contexts > 0 else native.default_streams(args.k, native.ALPHABET_NT2)
     ctxs = [native.Counter(k, native.ALPHABET_NT2, device=local) for _ in range(nctx)]
     ctx = ctxs[0]
     pool = ThreadPoolExecutor(nctx) if nctx > 1 else None

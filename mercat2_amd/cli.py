@@ -33,7 +33,8 @@ def parseargs(argv=None):
     p.add_argument("-o", type=str, default="mercat_results", required=False, help="Output folder")
     p.add_argument("-replace", action="store_true", help="Replace existing output directory [False]")
     p.add_argument("-gpu", type=int, default=0, help="HIP device index [0]")
-    p.add_argument("-streams", type=int, default=2, help="engine contexts counting chunks concurrently [2]")
+    p.add_argument("-streams", type=int, default=None,
+                   help="engine contexts counting chunks concurrently [2 for one-word keys, else 1]")
     p.add_argument("-canonical", action="store_true",
                    help="EXTENSION (not MerCat2 behaviour): count min(kmer, reverse complement) for nucleotide input")
     p.add_argument("--version", "-v", action="version", version=f"mercat2_amd {__version__}")

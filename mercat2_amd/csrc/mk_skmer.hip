@@ -33,10 +33,24 @@
 #define SK_SCAT_THREADS 1024
 #define SK_SCAT_SUBT 1
 #define SK_MAX_P1 8192
-#define SKC_SLOTS 8192
-#define SKC_LOADCAP (SKC_SLOTS / 2)
-#define SKC_TARGET (SKC_SLOTS * 4 / 10)
+#ifndef SKC_SLOTS
+#define SKC_SLOTS 8192          // LDS table slots of one workgroup (12 bytes each)
+#endif
+#ifndef SKC_THREADS
 #define SKC_THREADS 1024
+#endif
+#ifndef SKC_WGS
+#define SKC_WGS 1               // workgroups per CU the grid is sized for
+#endif
+#ifndef SKC_TARGET_PCT
+#define SKC_TARGET_PCT 40
+#endif
+#ifndef SKC_LB
+#define SKC_LB SKC_THREADS      // launch bound the register budget is derived from
+#endif
+#define SKC_PRE (2048 / SKC_THREADS)   // record batches (one record per thread each) per load round
+#define SKC_LOADCAP (SKC_SLOTS / 2)
+#define SKC_TARGET (SKC_SLOTS * SKC_TARGET_PCT / 100)
 #define SKC_SUB_BITS 16
 
 static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
@@ -46,10 +60,10 @@ static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 // the same 11-mer, and then either choice names the same minimizer. (The canonical mode relies on
 // this: a window and its reverse complement see the candidates in opposite order.)
 __device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {
-  unsigned h = (mm * 0x2C9277B5u) & SK_MASK;
+  // 24-bit multiplies (full rate on CDNA; a 32-bit v_mul_lo_u32 issues at a quarter of it): the low
+  // 22 bits of mm * odd + c are a bijection, the xor-shift folds the well-mixed high bits down.
+  unsigned h = (__umul24(mm, 0x9277B5u) + 0x2C5A3Du) & SK_MASK;
   h ^= h >> 11;
-  h = (h * 0x1B873593u) & SK_MASK;
-  h ^= h >> 13;
   return h;
 }
 // 11-mer under which a window is filed: itself, or min(itself, reverse complement) in canonical mode.
@@ -74,11 +88,13 @@ __device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
 // Windows j = 0..31 whose k bases are all clean, from the 64 bad bits that start at the thread's
 // first base (k <= 33: j + k - 1 <= 63).
 __device__ __forceinline__ unsigned sk_valid32(u64 badw, int k) {
-  const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
-  unsigned v = 0;
-#pragma unroll
-  for (int j = 0; j < SK_R; ++j) v |= (((badw >> j) & kmask) == 0) ? (1u << j) : 0u;
-  return v;
+  if (badw == 0) return ~0u;
+  // window j is clean iff bits j .. j+k-1 are: smear every bad bit down over the k-1 positions below it
+  u64 d = badw;
+  int cover = 1;
+  while (2 * cover <= k) { d |= d >> cover; cover *= 2; }
+  if (cover < k) d |= d >> (k - cover);
+  return ~(unsigned)d;
 }
 
 struct SkRuns {
@@ -292,8 +308,18 @@ __device__ __forceinline__ unsigned skc_hash(u64 key) {
 #define SKC_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
 // Linear probing from slot home+SKC_STEPS on (the caller has seen the first SKC_STEPS slots taken by other keys).
 #define SKC_STEPS 1  // batched probe steps before the serial loop
+// home slot of a hash and the slot d steps further (any table size; a power of two costs a shift and a mask)
+__device__ __forceinline__ unsigned skc_home(unsigned h) {
+  if constexpr ((SKC_SLOTS & (SKC_SLOTS - 1)) == 0) return h >> (32 - __builtin_ctz(SKC_SLOTS));
+  else return (unsigned)(((u64)h * SKC_SLOTS) >> 32);
+}
+__device__ __forceinline__ unsigned skc_step(unsigned slot, unsigned d) {
+  slot += d;
+  if constexpr ((SKC_SLOTS & (SKC_SLOTS - 1)) == 0) return slot & (SKC_SLOTS - 1);
+  else return slot >= SKC_SLOTS ? slot - SKC_SLOTS : slot;
+}
 __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
-  unsigned slot = ((h >> 19) + SKC_STEPS) & (SKC_SLOTS - 1);  // SKC_SLOTS == 8192
+  unsigned slot = skc_step(skc_home(h), SKC_STEPS);
   u64 cur = tkey[slot];
   for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
     if (cur == MK_EMPTY) {
@@ -301,7 +327,7 @@ __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s
       if (cur == MK_EMPTY) cur = key;
     }
     if (cur == key) { atomicAdd(&tcnt[slot], 1u); return; }
-    slot = (slot + 1) & (SKC_SLOTS - 1);
+    slot = skc_step(slot, 1);
     cur = tkey[slot];
   }
   atomicOr(s_overflow, 1u);  // (a plain volatile LDS store here trips a gfx950 backend assertion in ROCm 7.2)
@@ -320,7 +346,10 @@ __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s
 // Persistent: gridDim.x workgroups (one per CU) walk the buckets b = blockIdx.x, +gridDim.x, ...
 // The next bucket's bounds and its first two record batches are loaded while the current
 // bucket is being emitted, so no global-memory latency sits on the critical path.
-__global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
+#ifdef SKC_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(SKC_WAVES_PER_EU, SKC_WAVES_PER_EU)))
+#endif
+__global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
@@ -343,13 +372,15 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
   // prefetched state of the bucket about to be processed
   unsigned bn = blockIdx.x;
   u64 lo_n = 0, hi_n = 0, ks_n = 0;
-  ulonglong2 pre[2] = {make_ulonglong2(0, 0), make_ulonglong2(0, 0)};
+  ulonglong2 pre[SKC_PRE];
+#pragma unroll
+  for (int h = 0; h < SKC_PRE; ++h) pre[h] = make_ulonglong2(0, 0);
   if (bn < p1) {
     lo_n = start[bn];
     hi_n = start[bn + 1];
     ks_n = kstart[bn];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < SKC_PRE; ++h) {
       const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
       if (j < hi_n - lo_n) pre[h] = part[lo_n + j];
     }
@@ -358,7 +389,9 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
     const u64 lo = lo_n, n = hi_n - lo_n;  // records of this bucket
     u64* __restrict__ my_keys = out_keys + ks_n;
     u64* __restrict__ my_cnts = out_cnts + ks_n;
-    ulonglong2 first[2] = {pre[0], pre[1]};
+    ulonglong2 first[SKC_PRE];
+#pragma unroll
+    for (int h = 0; h < SKC_PRE; ++h) first[h] = pre[h];
     // bounds of the next bucket: in flight while this one is counted
     bn = b + gridDim.x;
     if (bn < p1) {
@@ -388,21 +421,21 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
         side_pass = 0;  // the all-ones key (32 x 'T') is counted aside, once per bucket
         bool over = false;
         unsigned* const ovf = &s_overflow[par];
-        for (u64 rb2 = 0; rb2 < n && !over; rb2 += 2 * SKC_THREADS) {
-          ulonglong2 recs2[2];
+        for (u64 rb2 = 0; rb2 < n && !over; rb2 += SKC_PRE * SKC_THREADS) {
+          ulonglong2 recs2[SKC_PRE];
           if (first_pass && rb2 == 0) {
-            recs2[0] = first[0];
-            recs2[1] = first[1];
+#pragma unroll
+            for (int h = 0; h < SKC_PRE; ++h) recs2[h] = first[h];
           } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < SKC_PRE; ++h) {
               const u64 j = rb2 + (u64)h * SKC_THREADS + threadIdx.x;
               recs2[h] = j < n ? src[j] : make_ulonglong2(0, 0);
             }
           }
           STAMP_ADD(tF, t0);
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < SKC_PRE; ++h) {
             // ---- one record per thread, expanded 8 k-mers at a time; the 8 first probes are
             //      issued together, the (rare) collisions and new keys take the slow path
             const ulonglong2 rec = recs2[h];
@@ -430,17 +463,17 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
               for (int step = 0; step < SKC_STEPS; ++step) {
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
-                  if (kk[u] != MK_EMPTY) cur[u] = tkey[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)];
+                  if (kk[u] != MK_EMPTY) cur[u] = tkey[skc_step(skc_home(hh[u]), step)];
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
                   if (kk[u] != MK_EMPTY && cur[u] == MK_EMPTY) {
-                    cur[u] = atomicCAS(&tkey[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)], MK_EMPTY, kk[u]);
+                    cur[u] = atomicCAS(&tkey[skc_step(skc_home(hh[u]), step)], MK_EMPTY, kk[u]);
                     if (cur[u] == MK_EMPTY) cur[u] = kk[u];
                   }
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
                   if (kk[u] != MK_EMPTY && cur[u] == kk[u]) {
-                    atomicAdd(&tcnt[((hh[u] >> 19) + step) & (SKC_SLOTS - 1)], 1u);
+                    atomicAdd(&tcnt[skc_step(skc_home(hh[u]), step)], 1u);
                     kk[u] = MK_EMPTY;  // resolved
                   }
               }
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
         }
         if (last && bn < p1) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < SKC_PRE; ++h) {
             const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
             pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
           }
@@ -531,7 +564,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_count_k(const ulonglong2* _
       // nothing was prefetched for the next bucket by a "last pass": do it here
       if (bn < p1) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < SKC_PRE; ++h) {
           const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
           pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
         }
@@ -623,7 +656,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
-    const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
+    const unsigned grid = (unsigned)((size_t)ncu * SKC_WGS < p1 ? (size_t)ncu * SKC_WGS : p1);
     u64* dbgbuf = nullptr;
 #ifdef MK_STAMP
     if (!mk_dbg_ptr) (void)hipMalloc((void**)&mk_dbg_ptr, 8 * 8 * 1024);

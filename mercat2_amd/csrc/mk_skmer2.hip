@@ -39,10 +39,8 @@ static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 #define SK_M 11
 #define SK_MASK ((1u << (2 * SK_M)) - 1)
 __device__ __forceinline__ unsigned sk2_order_hash(unsigned mm) {
-  unsigned h = (mm * 0x2C9277B5u) & SK_MASK;
+  unsigned h = (__umul24(mm, 0x9277B5u) + 0x2C5A3Du) & SK_MASK;  // 24-bit multiply: full rate (see mk_skmer.hip)
   h ^= h >> 11;
-  h = (h * 0x1B873593u) & SK_MASK;
-  h ^= h >> 13;
   return h;
 }
 __device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
@@ -129,6 +127,7 @@ __device__ __forceinline__ unsigned sk2_valid32(const u64* __restrict__ bad, siz
     b_lo = bad[bi];
     b_hi = bad[bi + 1];
   }
+  if ((b_lo | (b_hi & 0xFFFFFFFFull)) == 0) return ~0u;  // bits 0..95 are all the 32 windows can touch
   const u64 kmask = (k >= 64) ? ~0ull : ((1ull << k) - 1);
   unsigned v = 0;
 #pragma unroll

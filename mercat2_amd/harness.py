@@ -57,14 +57,14 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
-               *, device: int = 0, streams: int = 2, canonical: bool = False, threads: int = 0,
+               *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, threads: int = 0,
                stats: Optional[dict] = None, report=print) -> Tuple[str, Optional[os.PathLike]]:
     """chunk_files + run_mercat2 in one step with no chunk files (mk_count_file): native reader
     threads read (inflate) the file once into pinned blocks, the reference's cut rule is applied to
     the stream, and each chunk is copied to the GPU and counted (filtered on its own) while the next
     one is being read.  Same TSV as the two-step path.
 
-    ``streams`` contexts (HIP streams) take the chunks in turn and count concurrently; they are
+    ``streams`` contexts (HIP streams; default native.default_streams) take the chunks in turn and count concurrently; they are
     summed on the device at the end.  ``threads`` = reader threads for plain files (0: pick).
     ``canonical`` is the opt-in extension of mk_set_canonical (not reference behaviour).  If a dict
     is passed as ``stats`` it receives the mk_file_stats_t fields of the read.  ``report`` receives
@@ -72,6 +72,8 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
     chunk_bytes = max(0, int(chunk_mib)) * 1024 * 1024
     chunked = chunk_bytes > 0 and os.stat(file).st_size >= chunk_bytes
     alphabet = guess_alphabet(file, read_head(file))
+    if streams is None:
+        streams = native.default_streams(kmer, alphabet)
     n = max(1, int(streams)) if chunked else 1
     ctxs = [native.Counter(kmer, alphabet, device, canonical=canonical and alphabet == native.ALPHABET_NT2) for _ in range(n)]
     try:

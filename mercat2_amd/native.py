@@ -156,6 +156,15 @@ def chunk_cuts(text, chunksize: int) -> np.ndarray:
         cap = need.value
 
 
+def default_streams(k: int, alphabet: int) -> int:
+    """Contexts that pay off per GPU: a second one fills the gaps between the kernels of a chunk when
+    keys are one word (nucleotide k <= 32, protein k <= 12: measured +18 % on S2); with two-word keys
+    (33..64-mers) the long LDS-bound count kernels of two contexts only get in each other's way
+    (measured -30 % at k = 63), and the by-reference modes gain nothing."""
+    one_word = (alphabet == ALPHABET_NT2 and k <= 32) or (alphabet == ALPHABET_AA5 and k <= 12)
+    return 2 if one_word else 1
+
+
 def stream_cuts(text, chunksize: int, block: int) -> np.ndarray:
     """chunk_cuts through the streaming scanner of mk_count_file, the text handed over ``block`` bytes
     at a time; raises if the scanner lost, repeated or misplaced a byte."""
