@@ -382,6 +382,18 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   // filter (per chunk!) + merge
   if ((rc = mk_launch_count_survivors(c, min_count)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
+  if (c->h_info->part_overflow) {
+    // a bucket (or survivor) region sized from the sampled histogram was too small: the kernels stopped
+    // short of writing past it; partition and count again from the exact histogram
+    if (!c->part_sampled) { c->err = "partition overflow without sampling (internal error)"; return MK_ERR_STATE; }
+    MkChunkInfo* h = c->h_info;
+    if (getenv("MK_VERBOSE")) fprintf(stderr, "[mk] sampled partition too small (where=%llu: 1 records total, 2 survivors total, 4 a bucket, 8 a survivor region): exact pass\n", h->part_overflow);
+    h->windows = h->records = h->distinct = h->survivors = h->side = h->errors = h->part_overflow = 0;
+    MK_HIP(hipMemcpyAsync(c->info.p, h, sizeof(MkChunkInfo), hipMemcpyHostToDevice, c->stream));
+    c->st.part_retries += 1;
+    if ((rc = mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true)) != MK_OK) return rc;
+    if ((rc = pull_info(c)) != MK_OK) return rc;
+  }
   if (c->h_info->errors) {
     c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";
     return MK_ERR_RANGE;

@@ -54,7 +54,7 @@ struct MkChunkInfo {
   unsigned long long errors;        // non-zero: a kernel hit a condition it cannot handle
   unsigned long long parse_fallback;  // fast parser saw a blank in a sequence line: re-parse generally
   unsigned long long records;       // super-k-mer records written (partitioned nt path)
-  unsigned long long pad[1];
+  unsigned long long part_overflow; // a bucket region sized from a sampled histogram was too small: partition again, exactly
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
@@ -140,6 +140,7 @@ struct mk_ctx {
   int use_fast_parse = 1;
   int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)
   int use_superkmer = 1;
+  bool part_sampled = false;  // the last super-k-mer partition sized its buckets from a sample
   int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
   double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk
 
@@ -181,7 +182,7 @@ int mk_launch_count_ref128(mk_ctx* c, size_t seq_len);
 // partitioned hash64 path: windows -> hash buckets -> per-bucket LDS tables -> survivors (count >= min_count)
 int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip
-int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count);
+int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count);
 int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,

@@ -29,7 +29,15 @@
 #define SK_MASK ((1u << (2 * SK_M)) - 1)
 #define SK_R 32                 // windows per thread
 #define SK_NKMAX 8              // windows per record (<= 62 - k)
+#ifndef SK_HIST_THREADS
 #define SK_HIST_THREADS 256
+#endif
+#ifndef SK_ABL
+#define SK_ABL 0   // (timing experiments only)
+#endif
+#ifndef SK_HIST_GRID
+#define SK_HIST_GRID 512
+#endif
 #define SK_SCAT_THREADS 1024
 #define SK_SCAT_SUBT 1
 #define SK_MAX_P1 8192
@@ -184,29 +192,34 @@ __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart,
 }
 
 // ------------------------------------------------------------------------------ 1 hist
+// Records and k-mers per bucket.  With sample_log2 = s > 0 only one analysis thread of every 2^s
+// (a pseudo-random member of each group, so that no period of the text can hide from the sample)
+// is looked at: the scan below turns the sampled counts into capacities with room for the sampling
+// error, the scatter checks every reservation against them, and a chunk whose estimate was too
+// small anywhere is partitioned again with s = 0 (exact).
 template <int W>
 __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
-                                                                MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
+                                                                const MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                 u64* __restrict__ khist, int p1_log2, int k, int nkmax,
-                                                                size_t nthreads_total, int canon) {
+                                                                size_t nthreads_total, int canon, int sample_log2) {
   __shared__ unsigned lh[SK_MAX_P1];  // records per bucket
   __shared__ unsigned lk[SK_MAX_P1];  // k-mers per bucket (bounds the bucket's survivors)
   const unsigned p1 = 1u << p1_log2;
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) { lh[i] = 0; lk[i] = 0; }
   __syncthreads();
   const size_t seq_len = info->seq_len;
-  u64 mine = 0, recs = 0;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_total; t += (size_t)gridDim.x * blockDim.x) {
+  const size_t ngroups = (nthreads_total + ((size_t)1 << sample_log2) - 1) >> sample_log2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
+    size_t t = g;
+    if (sample_log2) t = (g << sample_log2) + (((unsigned)g * 0x9E3779B1u >> 7) & ((1u << sample_log2) - 1));
     const size_t p0 = t * SK_R;
-    if (p0 >= seq_len) break;
+    if (t >= nthreads_total || p0 >= seq_len) continue;
     const u64 w0 = codes[t], w1 = codes[t + 1];
     const u64 badw = bad_window(bad, p0);
     sk_for_each_record<W>(w0, w1, badw, k, nkmax, canon != 0, [&](int, int nk, unsigned mm) {
       const unsigned b = sk_bucket(mm, p1_log2);
       atomicAdd(&lh[b], 1u);
       atomicAdd(&lk[b], (unsigned)nk);
-      mine += (u64)nk;
-      ++recs;
     });
   }
   __syncthreads();
@@ -217,18 +230,75 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
       atomicAdd(&khist[b], (u64)lk[b]);
     }
   }
-  wave_add(&info->windows, mine);
-  wave_add(&info->records, recs);
+}
+
+// ------------------------------------------------------------------------------ 2 scan
+// Bucket regions of the record buffer (start/cursor) and of the survivor buffer (kstart) in one pass.
+// Exact histogram: a bucket gets exactly its records, and room for ceil(kmers / min_count) survivors
+// (no more entries than that can reach min_count).  Sampled histogram (S = 2^sample_log2): the
+// estimate S*h plus six standard deviations of it plus a floor.  The sampling unit is a thread, which
+// can put up to SK_R / SK_NKMAX records (SK_R k-mers) into one bucket, so the deviation is taken as
+// sqrt(S * estimate * that weight) -- measured: with weight 1 (as if records were sampled one by one) a
+// bucket in ~10^4 overflowed.  If the totals do not fit the buffers the chunk is flagged for the exact pass.
+__device__ __forceinline__ u64 sk_cap(u64 h, int sample_log2, u64 weight, double sigmas) {
+  if (sample_log2 == 0) return h;
+  const double est = (double)(h << sample_log2);
+  return (u64)(est + sigmas * __builtin_sqrt((double)((u64)weight << sample_log2) * est)) + (sigmas > 0 ? 16 * weight : 0);
+}
+__global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ hist, const u64* __restrict__ khist,
+                                                     u64* __restrict__ start, u64* __restrict__ cursor, u64* __restrict__ kstart,
+                                                     MkChunkInfo* __restrict__ info, int p1_log2, int sample_log2, int nkmax,
+                                                     u64 div, u64 part_cap, u64 surv_cap, double sigmas) {
+  __shared__ u64 sums[1024], ksums[1024];
+  const unsigned p1 = 1u << p1_log2;
+  const unsigned per = (p1 + 1023) / 1024;
+  const unsigned lo = threadIdx.x * per;
+  u64 acc = 0, kacc = 0;
+  for (unsigned i = lo; i < lo + per && i < p1; ++i) {
+    acc += sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas);
+    kacc += (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div;
+  }
+  sums[threadIdx.x] = acc;
+  ksums[threadIdx.x] = kacc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 run = 0, krun = 0;
+    for (int i = 0; i < 1024; ++i) {
+      const u64 v = sums[i], kv = ksums[i];
+      sums[i] = run;
+      ksums[i] = krun;
+      run += v;
+      krun += kv;
+    }
+    start[p1] = run;
+    kstart[p1] = krun;
+    if (run > part_cap) atomicOr(&info->part_overflow, 1ull);  // (only a sampled estimate can get here)
+    if (krun > surv_cap) atomicOr(&info->part_overflow, 2ull);
+  }
+  __syncthreads();
+  u64 run = sums[threadIdx.x], krun = ksums[threadIdx.x];
+  for (unsigned i = lo; i < lo + per && i < p1; ++i) {
+    start[i] = run;
+    cursor[i] = run;
+    kstart[i] = krun;
+    run += sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas);
+    krun += (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div;
+  }
 }
 
 // --------------------------------------------------------------------------- 3 scatter
 template <int W>
 __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
-                                                                   const MkChunkInfo* __restrict__ info,
+                                                                   MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                    u64* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                                    int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
   __shared__ unsigned lh[SK_MAX_P1];
   __shared__ u64 gbase[SK_MAX_P1];
+  __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
+  if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
+  __syncthreads();
+  if (s_abort) return;  // the regions do not fit the buffers: nothing may be written
+  unsigned spilled = 0;
   constexpr int NB = SK_MAX_P1 / SK_SCAT_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
@@ -270,7 +340,13 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        if (b < p1) { gbase[b] = r[i]; lh[b] = 0; }
+        if (b < p1) {
+          // a run that would cross the end of its bucket's region (sampled sizes only) is not written
+          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+          spilled |= fits ? 0u : 1u;
+          gbase[b] = fits ? r[i] : ~0ull;
+          lh[b] = 0;
+        }
       }
     }
     __syncthreads();
@@ -280,13 +356,16 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
       const u64 w0 = ww0[st], w1 = ww1[st];
       sk_walk(runs[st], w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
-        part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk_make_record(w0, w1, jstart, nk, k);
+        const u64 base = gbase[b];
+        const unsigned rank = atomicAdd(&lh[b], 1u);
+        if (base != ~0ull) part[base + rank] = sk_make_record(w0, w1, jstart, nk, k);
       });
     }
     __syncthreads();
     for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
     __syncthreads();
   }
+  if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
 
 // ------------------------------------------------------------------------------ 4 count
@@ -350,6 +429,7 @@ __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s
 __attribute__((amdgpu_waves_per_eu(SKC_WAVES_PER_EU, SKC_WAVES_PER_EU)))
 #endif
 __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
+                                                             const u64* __restrict__ cursor,
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
@@ -359,26 +439,34 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   __shared__ unsigned tcnt[SKC_SLOTS];
   // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
+  __shared__ unsigned long long s_windows;
+  __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
+  if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
+  __syncthreads();
+  if (s_abort) return;  // the scatter did not fit its (sampled) regions: the chunk is partitioned again
   for (unsigned i = threadIdx.x; i < SKC_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
   if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) s_windows = 0;
   __syncthreads();
   unsigned par = 0;
   const int kshift = 64 - 2 * k;
   const int lane = threadIdx.x & 63;
   u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
+  u64 windows = 0, records_total = 0;  // what the chunk held (every record is expanded at least once)
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, npass = 0;
   STAMP(t0);
 
   // prefetched state of the bucket about to be processed
   unsigned bn = blockIdx.x;
-  u64 lo_n = 0, hi_n = 0, ks_n = 0;
+  u64 lo_n = 0, hi_n = 0, ks_n = 0, ke_n = 0;  // records [lo_n, hi_n), survivor region [ks_n, ke_n)
   ulonglong2 pre[SKC_PRE];
 #pragma unroll
   for (int h = 0; h < SKC_PRE; ++h) pre[h] = make_ulonglong2(0, 0);
   if (bn < p1) {
     lo_n = start[bn];
-    hi_n = start[bn + 1];
+    hi_n = cursor[bn];
     ks_n = kstart[bn];
+    ke_n = kstart[bn + 1];
 #pragma unroll
     for (int h = 0; h < SKC_PRE; ++h) {
       const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
@@ -389,6 +477,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
     const u64 lo = lo_n, n = hi_n - lo_n;  // records of this bucket
     u64* __restrict__ my_keys = out_keys + ks_n;
     u64* __restrict__ my_cnts = out_cnts + ks_n;
+    const u64 region = ke_n - ks_n;
     ulonglong2 first[SKC_PRE];
 #pragma unroll
     for (int h = 0; h < SKC_PRE; ++h) first[h] = pre[h];
@@ -396,8 +485,9 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
     bn = b + gridDim.x;
     if (bn < p1) {
       lo_n = start[bn];
-      hi_n = start[bn + 1];
+      hi_n = cursor[bn];
       ks_n = kstart[bn];
+      ke_n = kstart[bn + 1];
     }
     unsigned emitted = 0;
     if (n >> 27) {  // 2^27 records x 31 k-mers would overflow the 32-bit LDS counters
@@ -412,13 +502,15 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
       }
       int s = s0;
       unsigned idx = 0;
-      u64 side_pass = 0;
+      records_total += n;
+      u64 side_pass = 0, win_pass = 0;
       bool side_done = false;
       bool first_pass = true;
       const ulonglong2* __restrict__ src = part + lo;
       for (;;) {
         const unsigned sel_shift = SKC_SUB_BITS - s;
         side_pass = 0;  // the all-ones key (32 x 'T') is counted aside, once per bucket
+        win_pass = 0;
         bool over = false;
         unsigned* const ovf = &s_overflow[par];
         for (u64 rb2 = 0; rb2 < n && !over; rb2 += SKC_PRE * SKC_THREADS) {
@@ -440,6 +532,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             //      issued together, the (rare) collisions and new keys take the slow path
             const ulonglong2 rec = recs2[h];
             const int nk = (int)(rec.y & 63);
+            win_pass += side_done ? 0 : (u64)nk;
             u64 x = rec.x, y = rec.y;
             for (int base = 0; base < nk; base += SKC_B) {
               u64 kk[SKC_B], cur[SKC_B];
@@ -528,9 +621,13 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           if (mine) {
             const unsigned at = emitted + atomicAdd(&s_emit[par], mine);  // LDS cursor inside the region
             unsigned o = 0;
+            if ((u64)at + mine > region) {  // only a region sized from a sampled histogram can be too small
+              atomicOr(&info->part_overflow, 8ull);
+              mine = 0;
+            }
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-              if (ek[q] != MK_EMPTY) {
+              if (mine && ek[q] != MK_EMPTY) {
                 my_keys[at + o] = ek[q];
                 my_cnts[at + o] = ec[q];
                 ++o;
@@ -549,6 +646,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           idx <<= 1;
         } else {
           side += side_pass;
+          windows += win_pass;
           side_done = true;
           while (s > s0 && (idx & 1u)) { idx >>= 1; --s; }
           if (s == s0) {
@@ -574,7 +672,14 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
     survivors_total += emitted;
     STAMP_ADD(tE, t0);
   }
+  {  // one global add per workgroup (adds to one address are serialised by the L2: ~4 ns each)
+    for (int d = 32; d > 0; d >>= 1) windows += __shfl_down(windows, d);
+    if (lane == 0 && windows) atomicAdd(&s_windows, (unsigned long long)windows);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
+    if (s_windows) atomicAdd(&info->windows, (u64)s_windows);
+    if (records_total) atomicAdd(&info->records, records_total);
     if (distinct_total) atomicAdd(&info->distinct, distinct_total);
     if (survivors_total) atomicAdd(&info->survivors, survivors_total);
     if (nerr) atomicAdd(&info->errors, nerr);
@@ -589,25 +694,30 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div);  // mk_part.hip
 
 template <int W>
-static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, u64* hist, u64* start, u64* cursor, u64* khist) {
-  (void)khist;
+static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
+                     u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
-  const size_t threads = div_up(seq_len, SK_R), tiles = div_up(threads, SK_HIST_THREADS);
+  double sigmas = 6.0;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
+  if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = atof(e);
+  const size_t threads = div_up(seq_len, SK_R);
+  const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end
-  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK_HIST_THREADS), 0, c->stream,
-                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical);
-  mk_launch_part_scan(c, hist, start, cursor, p1_log2, 1);
+  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < SK_HIST_GRID ? tiles : SK_HIST_GRID)), dim3(SK_HIST_THREADS), 0, c->stream,
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
+                     sample_log2);
+  hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
+                     info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
   hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
-                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (ulonglong2*)c->part.p, p1_log2,
-                     c->k, nkmax, stiles, c->canonical);
+                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
+                     (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
 }
 
 #ifdef MK_STAMP
 u64* mk_dbg_ptr = nullptr;
 #endif
 
-int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
+int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact) {
   if (seq_len == 0) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int k = c->k;
@@ -623,13 +733,33 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   int nkmax = 62 - k;
   if (nkmax > SK_NKMAX) nkmax = SK_NKMAX;
   if (const char* e = getenv("MK_NKMAX")) { int v = atoi(e); if (v >= 1 && v <= 31 && v <= 62 - k) nkmax = v; }
+  // Bucket sizes from a 1-in-2^s sample of the analysis threads (big chunks only: the exact histogram
+  // costs as much as the scatter's own analysis). MK_SAMPLE_LOG2=0 turns it off, MK_SAMPLE_MIN moves
+  // the size threshold (tests).
+  int sample_log2 = 0;
+  {
+    int want = 3;
+    size_t min_len = (size_t)8 << 20;
+    if (const char* e = getenv("MK_SAMPLE_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) want = v; }
+    if (const char* e = getenv("MK_SAMPLE_MIN")) min_len = (size_t)atoll(e);
+    if (!exact && seq_len >= min_len) sample_log2 = want;
+  }
+  c->part_sampled = sample_log2 != 0;
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   // worst case one record per window
-  if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(ulonglong2))) != MK_OK) return rc;
+  const size_t part_cap = seq_len + 64;
+  if ((rc = mk_buf_reserve(c, c->part, part_cap * sizeof(ulonglong2))) != MK_OK) return rc;
   // a bucket with m k-mers has at most ceil(m / min_count) survivors: that bounds its region
+  // (regions sized from a sample carry its error margin: half as much room again plus the per-bucket floor)
   const u64 surv_div = min_count > 1 ? (u64)min_count : 1;
-  const size_t surv_cap = seq_len / surv_div + p1 + 64;
+  size_t surv_cap = seq_len / surv_div + p1 + 64;
+  if (sample_log2) {
+    // sum over the buckets of (estimate + 6 sigma + floor) <= 1.25 L + 6 sqrt(p1 * S * SK_R * 1.25 L) + floor * p1
+    // (Cauchy-Schwarz on the sum of square roots; L = seq_len bounds the k-mers)
+    const double L = 1.25 * (double)seq_len, S = (double)(1u << sample_log2), w = (double)SK_R;
+    surv_cap = (size_t)((L + 6.0 * sqrt((double)p1 * S * w * L) + 16.0 * w * (double)p1) / (double)surv_div) + 2 * p1 + 64;
+  }
   if ((rc = mk_buf_reserve(c, c->surv_keys, surv_cap * sizeof(u64))) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
   u64* hist = (u64*)c->part_meta.p;
@@ -642,7 +772,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   mk_prof_begin(c, MK_K_PART);
   switch (k - SK_M + 1) {
-#define SK_CASE(W) case W: launch_w<W>(c, seq_len, p1_log2, nkmax, hist, start, cursor, khist); break;
+#define SK_CASE(W) case W: launch_w<W>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); break;
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
     SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
 #undef SK_CASE
@@ -650,7 +780,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
       c->err = "mk_launch_count_superkmer: k out of range";
       return MK_ERR_ARG;
   }
-  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2, surv_div);
+  (void)kcursor;
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {
@@ -663,7 +793,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     dbgbuf = mk_dbg_ptr;
 #endif
     hipLaunchKernelGGL(mk_sk_count_k, dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p,
-                       (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                       (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                        (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf,
                        getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0, c->canonical);
   }

@@ -6,6 +6,14 @@ from pathlib import Path
 
 import pytest
 
+# Some GPU tests put their inputs in HBM with torch.  PyTorch-ROCm brings its own copy of the HIP
+# runtime: it has to be the first one loaded into the process (torch sees no GPU when libmercat_hip.so
+# pulled in /opt/rocm's copy before it), so load it before any test touches the engine.
+try:
+    import torch  # noqa: F401
+except ImportError:  # CPU-only environments without torch still run the host tests
+    torch = None
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))

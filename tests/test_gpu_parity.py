@@ -536,3 +536,26 @@ def test_many_contexts_and_threads():
             ctx.count_chunk(small, 1)
             if i % 50 == 0:
                 assert ctx.to_dict() == want
+
+
+@pytest.mark.parametrize("sigmas,expect_retry", [("6", False), ("0", True)])
+def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_retry):
+    """Big chunks size their super-k-mer buckets from a 1-in-8 sample of the histogram; a chunk whose
+    sample was too small anywhere is partitioned again exactly.  Same tables either way (forced here on
+    a small input: MK_SAMPLE_MIN=0; MK_SAMPLE_SIGMAS=0 removes the safety margin so the second pass runs)."""
+    monkeypatch.setenv("MK_SAMPLE_MIN", "0")
+    monkeypatch.setenv("MK_SAMPLE_SIGMAS", sigmas)
+    data = native.synth_reads(200_000, 41, 60_000, 150, 42).tobytes()
+    low = b">poly\n" + b"A" * 30_000 + b"\n>rep\n" + b"ACGTTGCAAG" * 4_000 + b"\n"
+    from oracle import c_oracle
+    for k, c in ((21, 2), (31, 1), (32, 3)):
+        for payload in (data, data + low):
+            half = payload[: len(payload) // 2]
+            want = cpu_ref.merge_counts([c_oracle.count_dict(payload, k, c), c_oracle.count_dict(half, k, c)])
+            with native.Counter(k, native.ALPHABET_NT2) as ctx:
+                ctx.count_chunk(payload, c)
+                ctx.count_chunk(half, c)      # a second chunk on the same context
+                got = ctx.to_dict()
+                retries = ctx.stats()["part_retries"]
+            assert got == want, (k, c, sigmas)
+            assert (retries > 0) == expect_retry, (k, c, sigmas, retries)
