@@ -28,6 +28,19 @@ __device__ __forceinline__ void wave_add(u64* target, u64 mine) {
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(target, mine);
 }
 
+// One global add per workgroup (adds to one address are serialised by the L2, ~4 ns each: per-wave
+// adds from thousands of waves cost more than the kernels they end). Every thread must call it.
+__device__ __forceinline__ void block_add(u64* target, u64 mine) {
+  __shared__ unsigned long long s_block_sum;
+  if (threadIdx.x == 0) s_block_sum = 0;
+  __syncthreads();
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_block_sum, (unsigned long long)mine);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_block_sum) atomicAdd(target, (u64)s_block_sum);
+}
+
+
 // Reverse complement of a packed nucleotide key (k symbols, 2 bits each, A0 C1 G2 T3: the
 // complement of code c is 3-c, i.e. ~c). Bit-reverse the complemented word, put the two bits
 // of every symbol back in order, and shift the k symbols down.

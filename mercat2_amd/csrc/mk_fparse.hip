@@ -25,7 +25,10 @@
 typedef unsigned long long u64;
 
 #define FP_THREADS 256
-#define FP_SUB 4                       // 1 KiB sub-steps per wave
+#ifndef FP_SUB
+#define FP_SUB 8
+#endif
+// 1 KiB sub-steps per wave (8: a quarter of the entries for the single-workgroup scan than with 2, measured best)
 #define FP_WAVE_BYTES (FP_SUB * 1024)  // input bytes per wave
 #define FP_WAVES (FP_THREADS / 64)
 

@@ -73,8 +73,8 @@ __global__ __launch_bounds__(PART_THREADS) void mk_part_hist_k(const u64* __rest
     const unsigned v = lh[b];
     if (v) atomicAdd(&hist[b], (u64)v);
   }
-  wave_add(&info->windows, mine);
-  wave_add(&info->side, side);
+  block_add(&info->windows, mine);
+  wave_add(&info->side, side);  // (almost always zero: no add)
 }
 
 // -------------------------------------------------------------------------------- 2 scan

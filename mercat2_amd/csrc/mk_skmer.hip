@@ -38,7 +38,12 @@
 #ifndef SK_HIST_GRID
 #define SK_HIST_GRID 512
 #endif
+#ifndef SK_SCAT_THREADS
 #define SK_SCAT_THREADS 1024
+#endif
+#ifndef SK_SCAT_GRID
+#define SK_SCAT_GRID 4096
+#endif
 #define SK_SCAT_SUBT 1
 #define SK_MAX_P1 8192
 #ifndef SKC_SLOTS
@@ -240,60 +245,73 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
 // can put up to SK_R / SK_NKMAX records (SK_R k-mers) into one bucket, so the deviation is taken as
 // sqrt(S * estimate * that weight) -- measured: with weight 1 (as if records were sampled one by one) a
 // bucket in ~10^4 overflowed.  If the totals do not fit the buffers the chunk is flagged for the exact pass.
-__device__ __forceinline__ u64 sk_cap(u64 h, int sample_log2, u64 weight, double sigmas) {
+__device__ __forceinline__ u64 sk_cap(u64 h, int sample_log2, u64 weight, float sigmas) {
   if (sample_log2 == 0) return h;
-  const double est = (double)(h << sample_log2);
-  return (u64)(est + sigmas * __builtin_sqrt((double)((u64)weight << sample_log2) * est)) + (sigmas > 0 ? 16 * weight : 0);
+  const u64 est = h << sample_log2;
+  // single precision is plenty for a margin (the square root is rounded up by the +1)
+  const float dev = sigmas * __builtin_sqrtf((float)((u64)weight << sample_log2) * (float)est);
+  return est + (u64)dev + 1 + (sigmas > 0 ? 16 * weight : 0);
 }
 __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ hist, const u64* __restrict__ khist,
                                                      u64* __restrict__ start, u64* __restrict__ cursor, u64* __restrict__ kstart,
                                                      MkChunkInfo* __restrict__ info, int p1_log2, int sample_log2, int nkmax,
-                                                     u64 div, u64 part_cap, u64 surv_cap, double sigmas) {
-  __shared__ u64 sums[1024], ksums[1024];
+                                                     u64 div, u64 part_cap, u64 surv_cap, float sigmas) {
+  constexpr int PER = SK_MAX_P1 / 1024;  // buckets per thread (p1 <= SK_MAX_P1)
+  __shared__ u64 wsum[16], wksum[16];
   const unsigned p1 = 1u << p1_log2;
   const unsigned per = (p1 + 1023) / 1024;
   const unsigned lo = threadIdx.x * per;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  u64 cap[PER], kcap[PER];
   u64 acc = 0, kacc = 0;
-  for (unsigned i = lo; i < lo + per && i < p1; ++i) {
-    acc += sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas);
-    kacc += (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const unsigned i = lo + q;
+    const bool on = (unsigned)q < per && i < p1;
+    cap[q] = on ? sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas) : 0;
+    kcap[q] = on ? (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div : 0;
+    acc += cap[q];
+    kacc += kcap[q];
   }
-  sums[threadIdx.x] = acc;
-  ksums[threadIdx.x] = kacc;
+  // exclusive scan over the 1024 threads: inside each wave by shuffles, then over the 16 wave totals
+  u64 inc = acc, kinc = kacc;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const u64 a = __shfl_up(inc, d), b = __shfl_up(kinc, d);
+    if (lane >= d) { inc += a; kinc += b; }
+  }
+  if (lane == 63) { wsum[wv] = inc; wksum[wv] = kinc; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 run = 0, krun = 0;
-    for (int i = 0; i < 1024; ++i) {
-      const u64 v = sums[i], kv = ksums[i];
-      sums[i] = run;
-      ksums[i] = krun;
-      run += v;
-      krun += kv;
+  u64 run = inc - acc, krun = kinc - kacc;
+  for (int w = 0; w < wv; ++w) { run += wsum[w]; krun += wksum[w]; }
+  if (threadIdx.x == 1023) {
+    const u64 total = run + acc, ktotal = krun + kacc;
+    start[p1] = total;
+    kstart[p1] = ktotal;
+    if (total > part_cap) atomicOr(&info->part_overflow, 1ull);  // (only a sampled estimate can get here)
+    if (ktotal > surv_cap) atomicOr(&info->part_overflow, 2ull);
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const unsigned i = lo + q;
+    if ((unsigned)q < per && i < p1) {
+      start[i] = run;
+      cursor[i] = run;
+      kstart[i] = krun;
+      run += cap[q];
+      krun += kcap[q];
     }
-    start[p1] = run;
-    kstart[p1] = krun;
-    if (run > part_cap) atomicOr(&info->part_overflow, 1ull);  // (only a sampled estimate can get here)
-    if (krun > surv_cap) atomicOr(&info->part_overflow, 2ull);
-  }
-  __syncthreads();
-  u64 run = sums[threadIdx.x], krun = ksums[threadIdx.x];
-  for (unsigned i = lo; i < lo + per && i < p1; ++i) {
-    start[i] = run;
-    cursor[i] = run;
-    kstart[i] = krun;
-    run += sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas);
-    krun += (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div;
   }
 }
 
 // --------------------------------------------------------------------------- 3 scatter
 template <int W>
-__global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+__global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                    MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                    u64* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                                    int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
   __shared__ unsigned lh[SK_MAX_P1];
-  __shared__ u64 gbase[SK_MAX_P1];
+  __shared__ unsigned gbase[SK_MAX_P1];  // record index of the tile's run in each bucket (the launcher keeps indices below 2^32)
   __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+        r[i] = (v[i] && SK_ABL != 4) ? atomicAdd(&cursor[b], (u64)v[i]) : (SK_ABL == 4 ? start[b < p1 ? b : 0] : 0ull);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -344,7 +362,7 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
           // a run that would cross the end of its bucket's region (sampled sizes only) is not written
           const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
           spilled |= fits ? 0u : 1u;
-          gbase[b] = fits ? r[i] : ~0ull;
+          gbase[b] = fits ? (unsigned)r[i] : ~0u;
           lh[b] = 0;
         }
       }
@@ -356,9 +374,9 @@ __global__ __launch_bounds__(SK_SCAT_THREADS) void mk_sk_scatter_k(const u64* __
       const u64 w0 = ww0[st], w1 = ww1[st];
       sk_walk(runs[st], w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
-        const u64 base = gbase[b];
+        const unsigned base = gbase[b];
         const unsigned rank = atomicAdd(&lh[b], 1u);
-        if (base != ~0ull) part[base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+        if (base != ~0u && (SK_ABL != 3 || rank == 12345u)) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
       });
     }
     __syncthreads();
@@ -697,18 +715,19 @@ template <int W>
 static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
                      u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
-  double sigmas = 6.0;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
-  if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = atof(e);
+  float sigmas = 6.0f;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
+  if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = (float)atof(e);
   const size_t threads = div_up(seq_len, SK_R);
   const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
-  // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end
-  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < SK_HIST_GRID ? tiles : SK_HIST_GRID)), dim3(SK_HIST_THREADS), 0, c->stream,
+  // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
+  const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
+  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
                      sample_log2);
   hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
                      info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
-  hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK_SCAT_THREADS), 0,
+  hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
                      (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
 }

@@ -188,8 +188,8 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
       atomicAdd(&khist[b], (u64)lk[b]);
     }
   }
-  wave_add(&info->exotic, mine);  // these windows are counted outside the packed-key table: "by reference" totals
-  wave_add(&info->records, recs);
+  block_add(&info->exotic, mine);  // these windows are counted outside the packed-key table: "by reference" totals
+  block_add(&info->records, recs);
 }
 
 __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,

@@ -5,6 +5,7 @@
 // surviving dicts (bin/mercat2.py:121-127: kmers[k] += v).  The filter is applied per chunk,
 // before the merge -- there is no post-merge filter in the reference (SURVEY.md trap T2).
 #include "mk_common.h"
+#include "mk_device.h"
 
 typedef unsigned long long u64;
 #define REF_POS_BITS 40
@@ -33,11 +34,6 @@ int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots) {
 }
 
 // ------------------------------------------------------------------------------ survivors
-__device__ __forceinline__ void block_add(u64* target, u64 mine) {
-  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(target, mine);
-}
-
 __global__ void mk_count_survivors_k(const MkSlot* __restrict__ t, size_t slots, u64 min_count, u64* __restrict__ out) {
   u64 mine = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
