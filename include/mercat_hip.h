@@ -134,6 +134,20 @@ int mk_export(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t rows_cap);
  * table is empty (bin/mercat2.py:128-137). */
 int mk_write_tsv(mk_ctx* ctx, const char* path, const char* basename, size_t* rows);
 
+/* ---- several samples side by side: merge_tsv (lib/mercat2_report.py:98-156) from the tables --- */
+/* The combined table of n samples (contexts with the same k; each on its own GPU or all on one):
+ * every k-mer present in any of them, in sorted(str) order, with its count in each sample (0 where
+ * absent).  kmers: rows*k bytes, matrix: rows*n counts, row-major, both caller-allocated; call with
+ * kmers = matrix = NULL to get *rows. */
+int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* matrix, size_t rows_cap, size_t* rows);
+/* The same as the file merge_tsv writes: "<first_column>\t<names[0]>\t...\n" then one line per k-mer.
+ * names are the column titles, in the order of ctxs (the reference sorts the sample names). */
+int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
+                        const char* path, size_t* rows);
+/* Free the per-chunk working memory of a context and keep its running table (for samples that wait
+ * for mk_merged_export while others are being counted). */
+int mk_trim(mk_ctx* ctx);
+
 /* ---- multi-GPU merge plumbing (replaces ray.get + dict sum across workers) -------------- */
 /* Packed-key view of the running table for exchange over RCCL: *rows entries sorted by key
  * into caller-provided DEVICE buffers (words_per_key = 1 for hash64/dense, 2 for hash128).

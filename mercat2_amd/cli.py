@@ -16,6 +16,7 @@ from pathlib import Path
 
 from . import __version__
 from .harness import run_sample
+from .report import merge_counters
 
 FILE_EXT_NUCLEOTIDE = [".fasta", ".fa", ".fna", ".ffn", ".fasta.gz", ".fa.gz", ".fna.gz", ".ffn.gz"]
 FILE_EXT_PROTEIN = [".faa", ".faa.gz"]
@@ -92,11 +93,13 @@ def main(argv=None) -> int:
         # Samples are independent (bin/mercat2.py:336-339).  A '.gz' sample is bound by its one inflating
         # thread, so up to -n samples (at most 8) are in flight at once, each with its own contexts; the
         # lines the reference prints per sample are kept and shown in sample order.
+        tables = {}  # sample -> its table, kept on the GPU for the combined table
+
         def one(item):
             base, f = item
             lines = []
             run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
-                       streams=args.streams, canonical=args.canonical, report=lines.append)
+                       streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables)
             return lines
         workers = max(1, min(int(args.n), 8, len(samples[kind])))
         if workers == 1:
@@ -109,6 +112,14 @@ def main(argv=None) -> int:
             for line in lines:
                 print(line)
         print(f"Time to count {args.k}-mers: {round(timeit.default_timer() - start, 2)} seconds")
+        # combined_<type>.tsv: what createFigures writes first (bin/mercat2.py:146-150, merge_tsv), here
+        # straight from the tables; samples without significant k-mers are left out, as there
+        try:
+            if tables:
+                merge_counters(tables, out / ("combined_Nucleotide.tsv" if kind == "nucleotide" else "combined_protein.tsv"))
+        finally:
+            for t in tables.values():
+                t.close()
     return 0
 
 

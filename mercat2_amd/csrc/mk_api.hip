@@ -692,6 +692,149 @@ extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, s
   return MK_OK;
 }
 
+// ------------------------------------------------------------- combined table of several samples
+// merge_tsv (lib/mercat2_report.py:98-156) from the tables themselves: a k-way merge of the samples'
+// sorted rows (each: device radix sort of the packed keys + by-reference rows, as for mk_export).
+namespace {
+struct RowIter {  // the rows of one sample in sorted(str) order
+  const mk_ctx* c;
+  const ExportView* v;
+  size_t i = 0, j = 0;
+  std::vector<uint8_t> buf;
+  const uint8_t* cur = nullptr;
+  u64 cnt = 0;
+  RowIter(const mk_ctx* c_, const ExportView* v_) : c(c_), v(v_), buf((size_t)c_->k + 1) {}
+  bool next() {
+    const size_t k = (size_t)c->k, np = v->pkeys.size(), nr = v->rorder.size();
+    if (i >= np && j >= nr) { cur = nullptr; return false; }
+    bool take_packed;
+    if (i < np) decode_key(c, v->pkeys[i], buf.data());
+    if (i >= np) take_packed = false;
+    else if (j >= nr) take_packed = true;
+    else take_packed = memcmp(buf.data(), v->rstr.data() + v->rorder[j] * k, k) < 0;
+    if (take_packed) { cur = buf.data(); cnt = v->pcnts[i]; ++i; }
+    else { cur = v->rstr.data() + v->rorder[j] * k; cnt = v->rcnt[v->rorder[j]]; ++j; }
+    return true;
+  }
+};
+
+// f(kmer, counts[n]) for every k-mer present in any sample, in sorted order; absent = 0
+template <class F>
+int merged_samples(mk_ctx* const* ctxs, int n, F&& f) {
+  if (!ctxs || n < 1 || !ctxs[0]) return MK_ERR_ARG;
+  mk_ctx* c0 = ctxs[0];
+  for (int s = 0; s < n; ++s) {
+    if (!ctxs[s]) { c0->err = "merged table: a context is NULL"; return MK_ERR_ARG; }
+    if (ctxs[s]->k != c0->k) { c0->err = "merged table: contexts differ in k"; return MK_ERR_ARG; }
+    if (ctxs[s]->in_chunk) { c0->err = "merged table: a chunk is open"; return MK_ERR_STATE; }
+  }
+  std::vector<ExportView> views((size_t)n);
+  std::vector<RowIter> it;
+  it.reserve((size_t)n);
+  for (int s = 0; s < n; ++s) {
+    int rc = build_view(ctxs[s], views[s]);
+    if (rc) { if (s) c0->err = ctxs[s]->err; return rc; }
+    it.emplace_back(ctxs[s], &views[s]);
+    it.back().next();
+  }
+  const size_t k = (size_t)c0->k;
+  std::vector<u64> row((size_t)n);
+  std::vector<uint8_t> key(k + 1);
+  for (;;) {
+    const uint8_t* best = nullptr;
+    for (int s = 0; s < n; ++s)
+      if (it[s].cur && (!best || memcmp(it[s].cur, best, k) < 0)) best = it[s].cur;
+    if (!best) break;
+    memcpy(key.data(), best, k);
+    for (int s = 0; s < n; ++s) {
+      if (it[s].cur && memcmp(it[s].cur, key.data(), k) == 0) { row[s] = it[s].cnt; it[s].next(); }
+      else row[s] = 0;
+    }
+    f(key.data(), row.data());
+  }
+  return MK_OK;
+}
+}  // namespace
+
+extern "C" int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* matrix, size_t rows_cap, size_t* rows) {
+  if (!rows) return MK_ERR_ARG;
+  size_t at = 0;
+  bool short_cap = false;
+  const size_t k = ctxs && ctxs[0] ? (size_t)ctxs[0]->k : 0;
+  int rc = merged_samples(ctxs, n, [&](const uint8_t* s, const u64* counts) {
+    if (kmers && matrix) {
+      if (at < rows_cap) {
+        memcpy(kmers + at * k, s, k);
+        memcpy(matrix + at * (size_t)n, counts, (size_t)n * sizeof(u64));
+      } else short_cap = true;
+    }
+    ++at;
+  });
+  if (rc) return rc;
+  *rows = at;
+  if (short_cap) { ctxs[0]->err = "mk_merged_export: rows_cap too small"; return MK_ERR_RANGE; }
+  return MK_OK;
+}
+
+extern "C" int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
+                                   const char* path, size_t* rows_out) {
+  if (!ctxs || n < 1 || !ctxs[0] || !names || !first_column || !path) return MK_ERR_ARG;
+  mk_ctx* c = ctxs[0];
+  FILE* f = fopen(path, "wb");
+  if (!f) { c->err = std::string("mk_write_merged_tsv: cannot open ") + path; return MK_ERR_IO; }
+  std::vector<char> out;
+  out.reserve(1 << 22);
+  auto flush = [&]() {
+    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+  };
+  {
+    std::string head = first_column;
+    for (int s = 0; s < n; ++s) { head += '\t'; head += names[s] ? names[s] : ""; }
+    head += '\n';
+    out.insert(out.end(), head.begin(), head.end());
+  }
+  const size_t k = (size_t)c->k;
+  size_t rows = 0;
+  int rc = merged_samples(ctxs, n, [&](const uint8_t* s, const u64* counts) {
+    out.insert(out.end(), (const char*)s, (const char*)s + k);
+    for (int q = 0; q < n; ++q) {
+      out.push_back('\t');
+      u64 v = counts[q];
+      char num[24];
+      int len = 0;
+      do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+      while (len) out.push_back(num[--len]);
+    }
+    out.push_back('\n');
+    ++rows;
+    if (out.size() > (1u << 22) - 4096 - k - 24 * (size_t)n) flush();
+  });
+  flush();
+  const bool bad = ferror(f) != 0;
+  if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_merged_tsv: write failed: ") + path; return MK_ERR_IO; }
+  if (rc) return rc;
+  if (rows_out) *rows_out = rows;
+  return MK_OK;
+}
+
+// Give back the per-chunk working memory (raw text, packed words, partition and survivor buffers,
+// chunk tables); the running table stays, so the sample can still be exported or merged. The
+// buffers come back on the next chunk.
+extern "C" int mk_trim(mk_ctx* c) {
+  if (!c) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_trim: a chunk is open"; return MK_ERR_STATE; }
+  MK_HIP(hipSetDevice(c->device));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  MkDevBuf* scratch[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->ctab, &c->rtab_chunk, &c->part,
+                         &c->surv_keys, &c->surv_cnts, &c->surv_keys2, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp};
+  for (auto* b : scratch)
+    if (!(b == &c->ctab && c->mode == MK_MODE_DENSE)) buf_free(*b);  // the dense bins are allocated once, at mk_create
+  if (c->mode != MK_MODE_DENSE) c->ctab_slots = 0;
+  c->rtab_chunk_slots = 0;
+  if (c->ingest_ring) { (void)hipHostFree(c->ingest_ring); c->ingest_ring = nullptr; c->ingest_ring_bytes = 0; }
+  return MK_OK;
+}
+
 // ------------------------------------------------------------------- multi-GPU plumbing
 extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;

@@ -58,7 +58,7 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
                *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, threads: int = 0,
-               stats: Optional[dict] = None, report=print) -> Tuple[str, Optional[os.PathLike]]:
+               stats: Optional[dict] = None, report=print, keep: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
     """chunk_files + run_mercat2 in one step with no chunk files (mk_count_file): native reader
     threads read (inflate) the file once into pinned blocks, the reference's cut rule is applied to
     the stream, and each chunk is copied to the GPU and counted (filtered on its own) while the next
@@ -68,7 +68,9 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
     summed on the device at the end.  ``threads`` = reader threads for plain files (0: pick).
     ``canonical`` is the opt-in extension of mk_set_canonical (not reference behaviour).  If a dict
     is passed as ``stats`` it receives the mk_file_stats_t fields of the read.  ``report`` receives
-    the one line the reference prints per sample."""
+    the one line the reference prints per sample.  With a dict as ``keep`` the sample's table stays
+    on the GPU (``keep[basename]`` = its Counter, working memory released) when it has rows, for
+    ``report.merge_counters``; the caller closes it."""
     chunk_bytes = max(0, int(chunk_mib)) * 1024 * 1024
     chunked = chunk_bytes > 0 and os.stat(file).st_size >= chunk_bytes
     alphabet = guess_alphabet(file, read_head(file))
@@ -80,7 +82,11 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
         st = native.count_file(ctxs, file, chunk_bytes, min_count, threads)
         if stats is not None:
             stats.update(st)
-        return _finish(ctxs[0], basename, out_file, report)
+        result = _finish(ctxs[0], basename, out_file, report)
+        if keep is not None and result[1] is not None:
+            ctxs[0].trim()
+            keep[basename] = ctxs.pop(0)
+        return result
     finally:
         for c in ctxs:
             c.close()

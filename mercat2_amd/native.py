@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
+    "mk_merged_export", "mk_write_merged_tsv", "mk_trim",
 ]
 
 
@@ -110,6 +111,9 @@ def lib() -> C.CDLL:
         "mk_version": (C.c_char_p, []),
         "mk_count_file": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_int,
                                     C.POINTER(FileStats)]),
+        "mk_merged_export": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t, szp]),
+        "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
+        "mk_trim": (C.c_int, [vp]),
         "mk_stream_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
     }
     for name, (res, args) in sig.items():
@@ -195,6 +199,30 @@ def count_file(ctxs: Sequence["Counter"], path, chunk_bytes: int, min_count: int
     if rc:
         ctxs[0]._check(rc)
     return st.as_dict()
+
+
+def merged_export(ctxs: Sequence["Counter"]) -> Tuple[np.ndarray, np.ndarray]:
+    """(kmers (rows, k) uint8, matrix (rows, len(ctxs)) uint64): every k-mer of any sample in sorted
+    order with its count per sample, 0 where absent (mk_merged_export)."""
+    L = lib()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rows = C.c_size_t(0)
+    ctxs[0]._check(L.mk_merged_export(arr, len(ctxs), None, None, 0, C.byref(rows)))
+    kmers = np.empty((rows.value, ctxs[0].k), dtype=np.uint8)
+    matrix = np.empty((rows.value, len(ctxs)), dtype=np.uint64)
+    if rows.value:
+        ctxs[0]._check(L.mk_merged_export(arr, len(ctxs), kmers.ctypes.data, matrix.ctypes.data, rows.value, C.byref(rows)))
+    return kmers, matrix
+
+
+def write_merged_tsv(ctxs: Sequence["Counter"], names: Sequence[str], path, first_column: str = "k-mer") -> int:
+    """mk_write_merged_tsv: the file merge_tsv (lib/mercat2_report.py:98-156) writes, from the tables."""
+    L = lib()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    rows = C.c_size_t(0)
+    ctxs[0]._check(L.mk_write_merged_tsv(arr, len(ctxs), cn, first_column.encode(), os.fsencode(str(path)), C.byref(rows)))
+    return rows.value
 
 
 def synth_reads(genome_len: int, genome_seed: int, reads: int, read_len: int, read_seed: int,
@@ -312,6 +340,10 @@ class Counter:
 
     def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
         self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
+
+    def trim(self):
+        """Free the per-chunk working memory, keep the running table (mk_trim)."""
+        self._check(self._L.mk_trim(self._h))
 
     def merge_from(self, other: "Counter"):
         """Add every row of ``other`` (same GPU, alphabet, k) into this context, on the device."""

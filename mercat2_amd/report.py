@@ -1,0 +1,63 @@
+"""Drop-in for the table-merging step of lib/mercat2_report.py (``merge_tsv``, lines 98-156): the
+combined sample x k-mer table that feeds the reference's plots, PCA and beta diversity.
+
+``merge_counters`` builds it straight from the samples' tables on the GPU (no TSV re-read);
+``merge_tsv`` keeps the reference's signature (a dict of TSV paths) by loading the files into engine
+tables first.  Both write the same text as the reference: header ``<first column>\\t<sorted names>``,
+then every k-mer present in any sample in sorted order with 0 where a sample lacks it.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import native
+
+
+def merge_counters(counters: Dict[str, "native.Counter"], out_file, first_column: str = "k-mer") -> int:
+    """Write the combined table of ``{sample name: Counter}``; returns the number of k-mer rows."""
+    names = sorted(counters.keys())
+    if not names:
+        raise ValueError("merge_counters: no samples")
+    return native.write_merged_tsv([counters[n] for n in names], names, out_file, first_column)
+
+
+def _load_tsv(path) -> tuple:
+    """(first header field, kmers (rows, k) uint8, counts uint64) of a count table."""
+    with open(path, "rb") as fh:
+        head = fh.readline().decode().split("\t")[0]
+        body = fh.read()
+    if not body.strip():
+        return head, np.zeros((0, 0), np.uint8), np.zeros(0, np.uint64)
+    lines = body.split(b"\n")
+    if not lines[-1]:
+        lines.pop()
+    k = lines[0].index(b"\t")
+    flat = np.frombuffer(b"".join(l[:k] for l in lines), dtype=np.uint8).reshape(len(lines), k)
+    counts = np.array([int(l[k + 1:]) for l in lines], dtype=np.uint64)
+    return head, flat, counts
+
+
+def merge_tsv(tsv_list: Dict[str, os.PathLike], out_file: os.PathLike, *, device: int = 0) -> None:
+    """merge_tsv(tsv_list, out_file) of lib/mercat2_report.py:98-156 (same arguments)."""
+    names = sorted(tsv_list.keys())
+    header: Optional[str] = None
+    ctxs = []
+    try:
+        loaded = []
+        for name in names:
+            head, kmers, counts = _load_tsv(tsv_list[name])
+            if header is None:
+                header = head
+            loaded.append((kmers, counts))
+        k = next((km.shape[1] for km, _ in loaded if km.size), 1)
+        for kmers, counts in loaded:
+            c = native.Counter(k, native.ALPHABET_RAW, device)
+            ctxs.append(c)
+            c.import_exotic(kmers, counts)
+        native.write_merged_tsv(ctxs, names, out_file, header or "k-mer")
+    finally:
+        for c in ctxs:
+            c.close()

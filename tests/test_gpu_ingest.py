@@ -181,3 +181,28 @@ def test_cli_folder_of_samples_in_parallel(tmp_path, capsys):
             assert not tsv.exists()
     assert printed.count("Significant k-mers:") + printed.count("No significant k-mers found") == len(names)
     assert printed.count("Time to count 4-mers:") == 2
+
+
+def test_cli_writes_the_combined_table(tmp_path, capsys):
+    """combined_<type>.tsv next to the per-sample tables (bin/mercat2.py:146-150): sorted sample names,
+    sorted k-mers, 0 where a sample lacks one; samples without rows are left out."""
+    import shutil
+    from mercat2_amd import cli
+    folder = tmp_path / "in"
+    folder.mkdir()
+    names = ["A.fasta", "B.fasta", "C.fasta", "edge_empty.fa"]
+    for n in names:
+        shutil.copy(GOLDEN / "inputs" / n, folder / n)
+    out = tmp_path / "res"
+    assert cli.main(["-f", str(folder), "-k", "6", "-c", "2", "-n", "2", "-o", str(out)]) == 0
+    capsys.readouterr()
+    tables = {}
+    for n in names:
+        t = cpu_ref.count_text((folder / n).read_bytes(), 6, 2)
+        if t:
+            tables[Path(n).stem] = t
+    cols = sorted(tables)
+    keys = sorted(set().union(*[set(t) for t in tables.values()]))
+    want = "k-mer\t" + "\t".join(cols) + "\n" + "".join(
+        key + "\t" + "\t".join(str(tables[c].get(key, 0)) for c in cols) + "\n" for key in keys)
+    assert (out / "combined_Nucleotide.tsv").read_text() == want
