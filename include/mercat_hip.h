@@ -144,6 +144,17 @@ int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* matri
  * names are the column titles, in the order of ctxs (the reference sorts the sample names). */
 int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
                         const char* path, size_t* rows);
+/* ---- alpha diversity of a sample: the moments of its count column (lib/mercat2_diversity.py:13-53
+ *      computes nine scikit-bio metrics from exactly these), reduced on the GPU ------------------ */
+typedef struct mk_alpha_t {
+  uint64_t observed; /* rows (distinct k-mers)                                   */
+  uint64_t total;    /* sum of the counts                                        */
+  uint64_t freq[11]; /* freq[i], i = 1..10: rows whose count is i (freq[0] unused) */
+  double sum_sq;     /* sum of count^2                                           */
+  double sum_clnc;   /* sum of count * ln(count)                                 */
+} mk_alpha_t;
+int mk_alpha_stats(mk_ctx* ctx, mk_alpha_t* out);
+
 /* Free the per-chunk working memory of a context and keep its running table (for samples that wait
  * for mk_merged_export while others are being counted). */
 int mk_trim(mk_ctx* ctx);

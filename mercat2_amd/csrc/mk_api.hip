@@ -817,6 +817,34 @@ extern "C" int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const
   return MK_OK;
 }
 
+// ------------------------------------------------------------------------ alpha diversity
+extern "C" int mk_alpha_stats(mk_ctx* c, mk_alpha_t* out) {
+  if (!c || !out) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_alpha_stats: a chunk is open"; return MK_ERR_STATE; }
+  MK_HIP(hipSetDevice(c->device));
+  int rc;
+  if ((rc = mk_buf_reserve(c, c->ex_tmp, 16 * sizeof(u64))) != MK_OK) return rc;
+  if ((rc = mk_launch_alpha(c, (unsigned long long*)c->ex_tmp.p)) != MK_OK) return rc;
+  u64 h[16];
+  MK_HIP(hipMemcpyAsync(h, c->ex_tmp.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  memset(out, 0, sizeof *out);
+  out->observed = h[0];
+  out->total = h[1];
+  for (int i = 1; i <= 10; ++i) out->freq[i] = h[2 + i];
+  memcpy(&out->sum_sq, &h[13], 8);
+  memcpy(&out->sum_clnc, &h[14], 8);
+  if (c->run_side) {  // the one key that lives beside the packed table (32 x 'T')
+    const u64 v = c->run_side;
+    out->observed += 1;
+    out->total += v;
+    if (v <= 10) out->freq[v] += 1;
+    out->sum_sq += (double)v * (double)v;
+    out->sum_clnc += (double)v * log((double)v);
+  }
+  return MK_OK;
+}
+
 // Give back the per-chunk working memory (raw text, packed words, partition and survivor buffers,
 // chunk tables); the running table stays, so the sample can still be exported or merged. The
 // buffers come back on the next chunk.

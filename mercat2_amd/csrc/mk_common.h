@@ -190,6 +190,7 @@ int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_
 // tables
 int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
 int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);
+int mk_launch_alpha(mk_ctx* c, unsigned long long* d_out);  // 16 words: see mk_alpha_k
 int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);

@@ -399,3 +399,70 @@ int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
+
+// ------------------------------------------------------------------- alpha-diversity moments
+// One pass over the running table(s): everything the nine alpha metrics of lib/mercat2_diversity.py:13-53
+// need from the count column (out[0] rows, out[1] sum c, out[2..12] rows with count 0..10 (slot 2 unused),
+// then as doubles out[13] sum c^2, out[14] sum c ln c).
+__device__ __forceinline__ void alpha_take(u64 c, u64& rows, u64& total, double& sq, double& clnc, unsigned* s_freq) {
+  if (!c) return;
+  rows += 1;
+  total += c;
+  const double d = (double)c;
+  sq += d * d;
+  clnc += d * log(d);
+  if (c <= 10) atomicAdd(&s_freq[c], 1u);
+}
+__global__ __launch_bounds__(256) void mk_alpha_k(const MkSlot* __restrict__ slots, size_t nslots, const u64* __restrict__ bins,
+                                                  size_t nbins, u64* __restrict__ out) {
+  __shared__ unsigned s_freq[11];
+  __shared__ unsigned long long s_rows, s_total;
+  __shared__ double s_sq, s_clnc;
+  if (threadIdx.x < 11) s_freq[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_rows = 0; s_total = 0; s_sq = 0; s_clnc = 0; }
+  __syncthreads();
+  u64 rows = 0, total = 0;
+  double sq = 0, clnc = 0;
+  const size_t stride = (size_t)gridDim.x * blockDim.x, first = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (size_t i = first; i < nslots; i += stride) {
+    const ulonglong2 s = reinterpret_cast<const ulonglong2*>(slots)[i];
+    if (s.x != MK_EMPTY) alpha_take(s.y, rows, total, sq, clnc, s_freq);
+  }
+  for (size_t i = first; i < nbins; i += stride) alpha_take(bins[i], rows, total, sq, clnc, s_freq);
+  for (int d = 32; d > 0; d >>= 1) {
+    rows += __shfl_down(rows, d);
+    total += __shfl_down(total, d);
+    sq += __shfl_down(sq, d);
+    clnc += __shfl_down(clnc, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_rows, (unsigned long long)rows);
+    atomicAdd(&s_total, (unsigned long long)total);
+    atomicAdd(&s_sq, sq);
+    atomicAdd(&s_clnc, clnc);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_rows) atomicAdd(&out[0], (u64)s_rows);
+    if (s_total) atomicAdd(&out[1], (u64)s_total);
+    if (s_sq != 0) atomicAdd(reinterpret_cast<double*>(&out[13]), s_sq);
+    if (s_clnc != 0) atomicAdd(reinterpret_cast<double*>(&out[14]), s_clnc);
+  }
+  if (threadIdx.x < 11 && s_freq[threadIdx.x]) atomicAdd(&out[2 + threadIdx.x], (u64)s_freq[threadIdx.x]);
+}
+
+int mk_launch_alpha(mk_ctx* c, u64* d_out) {
+  MK_HIP(hipMemsetAsync(d_out, 0, 16 * sizeof(u64), c->stream));
+  if (c->mode == MK_MODE_DENSE) {
+    hipLaunchKernelGGL(mk_alpha_k, dim3(grid_for(c->run_slots, 256, 1024)), dim3(256), 0, c->stream, (const MkSlot*)nullptr,
+                       (size_t)0, (const u64*)c->run.p, c->run_slots, d_out);
+  } else if (c->run_slots) {
+    hipLaunchKernelGGL(mk_alpha_k, dim3(grid_for(c->run_slots, 256, 1024)), dim3(256), 0, c->stream, (const MkSlot*)c->run.p,
+                       c->run_slots, (const u64*)nullptr, (size_t)0, d_out);
+  }
+  if (c->run_ref_slots)
+    hipLaunchKernelGGL(mk_alpha_k, dim3(grid_for(c->run_ref_slots, 256, 1024)), dim3(256), 0, c->stream,
+                       (const MkSlot*)c->run_ref.p, c->run_ref_slots, (const u64*)nullptr, (size_t)0, d_out);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
-    "mk_merged_export", "mk_write_merged_tsv", "mk_trim",
+    "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats",
 ]
 
 
@@ -62,6 +62,12 @@ class FileStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
+
+
+class AlphaStats(C.Structure):
+    """mk_alpha_t (include/mercat_hip.h)."""
+    _fields_ = [("observed", C.c_uint64), ("total", C.c_uint64), ("freq", C.c_uint64 * 11),
+                ("sum_sq", C.c_double), ("sum_clnc", C.c_double)]
 
 
 _LIB: Optional[C.CDLL] = None
@@ -114,6 +120,7 @@ def lib() -> C.CDLL:
         "mk_merged_export": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t, szp]),
         "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
         "mk_trim": (C.c_int, [vp]),
+        "mk_alpha_stats": (C.c_int, [vp, C.POINTER(AlphaStats)]),
         "mk_stream_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
     }
     for name, (res, args) in sig.items():
@@ -340,6 +347,13 @@ class Counter:
 
     def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
         self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
+
+    def alpha_stats(self) -> dict:
+        """Moments of the count column, reduced on the GPU (mk_alpha_stats)."""
+        a = AlphaStats()
+        self._check(self._L.mk_alpha_stats(self._h, C.byref(a)))
+        return {"observed": int(a.observed), "total": int(a.total), "freq": [int(x) for x in a.freq],
+                "sum_sq": float(a.sum_sq), "sum_clnc": float(a.sum_clnc)}
 
     def trim(self):
         """Free the per-chunk working memory, keep the running table (mk_trim)."""
