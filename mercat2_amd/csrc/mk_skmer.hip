@@ -44,7 +44,9 @@
 #ifndef SK_SCAT_GRID
 #define SK_SCAT_GRID 4096
 #endif
-#define SK_SCAT_SUBT 1
+#ifndef SK_SCAT_SUBT
+#define SK_SCAT_SUBT 2
+#endif
 #define SK_MAX_P1 8192
 #ifndef SKC_SLOTS
 #define SKC_SLOTS 8192          // LDS table slots of one workgroup (12 bytes each)
@@ -312,6 +314,10 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
                                                                    int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
   __shared__ unsigned lh[SK_MAX_P1];
   __shared__ unsigned gbase[SK_MAX_P1];  // record index of the tile's run in each bucket (the launcher keeps indices below 2^32)
+  constexpr int PK = SK_SCAT_SUBT > 1 ? SK_SCAT_SUBT - 1 : 1;  // parked analyses (56 bytes per thread each)
+  __shared__ uint2 pk_mask[PK][SK_SCAT_THREADS];
+  __shared__ ulonglong2 pk_w[PK][SK_SCAT_THREADS];
+  __shared__ ulonglong2 pk_pos[PK][2][SK_SCAT_THREADS];
   __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
@@ -323,22 +329,31 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    // pass 1: analyse every sub-tile once (kept in registers for pass 2) and size the runs
-    SkRuns runs[SK_SCAT_SUBT];
-    u64 ww0[SK_SCAT_SUBT], ww1[SK_SCAT_SUBT];
+    // pass 1: analyse every sub-tile once and size the runs. The analysis of the last sub-tile stays
+    // in registers for pass 2, that of the others is parked in LDS (a second register copy spills):
+    // twice the records per tile halves the cursor atomics per record, which run at the L2's limit.
+    SkRuns runs;
+    u64 ww0 = 0, ww1 = 0;
 #pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
       const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
       const size_t p0 = t * SK_R;
-      runs[st].valid = 0;
-      runs[st].starts = 0;
-      ww0[st] = ww1[st] = 0;
+      runs.valid = 0;
+      runs.starts = 0;
+      runs.pos[0] = runs.pos[1] = runs.pos[2] = runs.pos[3] = 0;
+      ww0 = ww1 = 0;
       if (p0 < seq_len) {
-        ww0[st] = codes[t];
-        ww1[st] = codes[t + 1];
-        runs[st] = sk_analyse<W>(ww0[st], ww1[st], sk_valid32(bad_window(bad, p0), k), canon != 0);
-        sk_walk(runs[st], ww0[st], ww1[st], nkmax, canon != 0,
+        ww0 = codes[t];
+        ww1 = codes[t + 1];
+        runs = sk_analyse<W>(ww0, ww1, sk_valid32(bad_window(bad, p0), k), canon != 0);
+        sk_walk(runs, ww0, ww1, nkmax, canon != 0,
                 [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+      }
+      if (st + 1 < SK_SCAT_SUBT) {
+        pk_mask[st][threadIdx.x] = make_uint2(runs.valid, runs.starts);
+        pk_w[st][threadIdx.x] = make_ulonglong2(ww0, ww1);
+        pk_pos[st][0][threadIdx.x] = make_ulonglong2(runs.pos[0], runs.pos[1]);
+        pk_pos[st][1][threadIdx.x] = make_ulonglong2(runs.pos[2], runs.pos[3]);
       }
     }
     __syncthreads();
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        r[i] = (v[i] && SK_ABL != 4) ? atomicAdd(&cursor[b], (u64)v[i]) : (SK_ABL == 4 ? start[b < p1 ? b : 0] : 0ull);
+        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -368,15 +383,24 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
       }
     }
     __syncthreads();
-    // pass 2: rank of every record inside its run, store
+    // pass 2: rank of every record inside its run, store (registers first, then the parked sub-tiles)
 #pragma unroll
-    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
-      const u64 w0 = ww0[st], w1 = ww1[st];
-      sk_walk(runs[st], w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
+    for (int st = SK_SCAT_SUBT - 1; st >= 0; --st) {
+      if (st + 1 < SK_SCAT_SUBT) {
+        const uint2 m = pk_mask[st][threadIdx.x];
+        const ulonglong2 w = pk_w[st][threadIdx.x], pa = pk_pos[st][0][threadIdx.x], pb = pk_pos[st][1][threadIdx.x];
+        runs.valid = m.x;
+        runs.starts = m.y;
+        runs.pos[0] = pa.x; runs.pos[1] = pa.y; runs.pos[2] = pb.x; runs.pos[3] = pb.y;
+        ww0 = w.x;
+        ww1 = w.y;
+      }
+      const u64 w0 = ww0, w1 = ww1;
+      sk_walk(runs, w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
         const unsigned base = gbase[b];
         const unsigned rank = atomicAdd(&lh[b], 1u);
-        if (base != ~0u && (SK_ABL != 3 || rank == 12345u)) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+        if (base != ~0u) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
       });
     }
     __syncthreads();
