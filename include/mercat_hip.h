@@ -191,6 +191,13 @@ int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, uint64_t* c
  * misplaced a byte). */
 int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts, size_t cap,
                    size_t* ncuts);
+/* The file reader's own gzip decoder (csrc/mk_inflate.h) over a whole '.gz' file held in memory,
+ * producing `block` bytes per step as the reader does, every member's CRC-32 and length checked.
+ * A self-check for tests (against zlib): out must hold the whole text (cap bytes).
+ * MK_ERR_IO: corrupt or not gzip, MK_ERR_RANGE: truncated, MK_ERR_NOMEM: cap too small. */
+int mk_gunzip(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t block, size_t* written, int* members);
+/* zlib's crc32(seed, p, n) as the gzip reader computes it (carry-less multiplies; csrc/mk_crc32.h). */
+uint32_t mk_crc32_of(const uint8_t* p, size_t n, uint32_t seed);
 /* Deterministic synthetic reads: genome of `genome_len` iid ACGT from
  * splitmix64(genome_seed); `reads` reads of `read_len` from uniform starts, reverse-complemented
  * on a coin flip, per-base substitution with probability sub_ppm/1e6, all from

@@ -7,6 +7,8 @@
 #include <vector>
 #include "../../include/mercat_hip.h"
 #include "mk_cutscan.h"
+#include "mk_inflate.h"
+#include "mk_crc32.h"
 
 // ---------------------------------------------------------------------------- virtual Chunker
 // Restates Chunker.stream_delim (lib/mercat2_Chunker.py:39-59) without writing chunk files:
@@ -86,6 +88,37 @@ extern "C" int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize,
   for (size_t i = 0; i < sink.cuts.size() && i < cap && cuts; ++i) cuts[i] = sink.cuts[i];
   return (sink.cuts.size() > cap && cuts) ? MK_ERR_RANGE : MK_OK;
 }
+
+// ------------------------------------------------------------------------------- gunzip
+// The reader's own gzip decoder (mk_inflate.h) over a whole file in memory, producing `block` bytes
+// per call as the file reader does, with every member's CRC-32 and length checked (zlib's crc32).
+// A self-check for tests (against zlib / gzip.py); `out` must hold the whole text.
+extern "C" int mk_gunzip(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t block, size_t* written, int* members) {
+  if (!written || (n && !gz) || block == 0) return MK_ERR_ARG;
+  MkGzReader rd(gz, n);
+  size_t at = 0, member_start = 0;
+  for (;;) {
+    size_t got = 0;
+    const size_t room = cap - at < block ? cap - at : block;
+    const MkGzReader::Status s = rd.fill(out + at, out + at + room, out, &got);
+    at += got;
+    if (s == MkGzReader::END) break;
+    if (s != MkGzReader::MORE) return s == MkGzReader::TRUNCATED ? MK_ERR_RANGE : MK_ERR_IO;
+    if (rd.member_ended()) {
+      const uint32_t crc = mk_crc32(0, out + member_start, at - member_start);
+      if (crc != rd.member_crc() || (uint32_t)(at - member_start) != rd.member_isize()) return MK_ERR_IO;
+      member_start = at;
+    } else if (got == 0 && room == 0) {
+      return MK_ERR_NOMEM;  // cap too small
+    }
+  }
+  *written = at;
+  if (members) *members = rd.members();
+  return MK_OK;
+}
+
+// CRC-32 as the gzip reader computes it (mk_crc32.h), for tests against zlib.crc32.
+extern "C" uint32_t mk_crc32_of(const uint8_t* p, size_t n, uint32_t seed) { return mk_crc32(seed, p, n); }
 
 // ------------------------------------------------------------------------- synthetic reads
 static inline uint64_t splitmix64(uint64_t& s) {

@@ -23,7 +23,7 @@ def main():
         gz = path + ".gz"
         print("gzip -1 -> %.2f GB in %.1f s" % (os.path.getsize(gz) / 1e9, time.perf_counter() - t0))
     for f in [path] + ([gz] if gz else []):
-        for streams, threads in ((1, 0), (2, 0), (2, 2), (2, 16)):
+        for streams, threads in (((1, 0), (2, 0), (2, 2), (2, 16)) if not f.endswith('.gz') else ((2, 0), (2, 0), (2, 0))):
             for rep in range(2):
                 out = os.path.join(d, "S2_counts_%d.tsv" % streams)
                 st = {}
