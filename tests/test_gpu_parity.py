@@ -559,3 +559,33 @@ def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_
                 retries = ctx.stats()["part_retries"]
             assert got == want, (k, c, sigmas)
             assert (retries > 0) == expect_retry, (k, c, sigmas, retries)
+
+
+def test_skewed_genome_like_input_at_scale_vs_c_oracle():
+    """60 MB that look like an assembly rather than reads: megabase single-line records, a satellite
+    array (171-bp unit, 1 % mutated copies), poly-A, a dinucleotide repeat and N gaps next to random
+    sequence and reads.  The sampled bucket sizes are badly off where the repeats sit (exact second pass),
+    some buckets hold hundreds of thousands of windows of a handful of k-mers, others need sub-range
+    splitting; the table must still be the C oracle's, bit for bit."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    rand = lambda n: acgt[rng.integers(0, 4, n)].tobytes()
+    unit = rand(171)
+    sat = bytearray(unit * 50_000)
+    for pos in rng.integers(0, len(sat), len(sat) // 100):
+        sat[pos] = acgt[rng.integers(0, 4)]
+    genome = rand(20_000_000)
+    reads = native.synth_reads(2_000_000, 5, 150_000, 150, 6).tobytes()
+    parts = [b">chr1 random\n", genome[:12_000_000], b"\n>sat\n", bytes(sat), b"\n>polyA\n", b"A" * 1_000_000,
+             b"\n>ac\n", b"AC" * 1_000_000, b"\n>gaps\n", genome[12_000_000:16_000_000], b"N" * 5000,
+             genome[16_000_000:], b"\n", reads, b">chr1_again\n", genome[:6_000_000], b"\n"]
+    data = b"".join(parts)
+    for k, c in ((31, 2), (21, 3)):
+        okm, ocn = c_oracle.count(data, k, c)
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, c)
+            kmers, counts = ctx.export()
+            st = ctx.stats()
+        assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), (k, c)
+        assert st["windows"] > 50_000_000
