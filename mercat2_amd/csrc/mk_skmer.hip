@@ -63,6 +63,9 @@
 #ifndef SKC_LB
 #define SKC_LB SKC_THREADS      // launch bound the register budget is derived from
 #endif
+#ifndef SKC_CAS_FIRST
+#define SKC_CAS_FIRST 1  // claim-or-compare with ONE compare-and-swap per key instead of read + conditional swap: the insert is bound by LDS instruction issue, not by active lanes (count kernel -5 %)
+#endif
 #define SKC_PRE (2048 / SKC_THREADS)   // record batches (one record per thread each) per load round
 #define SKC_LOADCAP (SKC_SLOTS / 2)
 #define SKC_TARGET (SKC_SLOTS * SKC_TARGET_PCT / 100)
@@ -596,6 +599,14 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               // slot holds it; what is still unresolved after the last step (a few %) probes serially.
 #pragma unroll
               for (int step = 0; step < SKC_STEPS; ++step) {
+#if SKC_CAS_FIRST
+#pragma unroll
+                for (int u = 0; u < SKC_B; ++u)
+                  if (kk[u] != MK_EMPTY) {
+                    cur[u] = atomicCAS(&tkey[skc_step(skc_home(hh[u]), step)], MK_EMPTY, kk[u]);
+                    if (cur[u] == MK_EMPTY) cur[u] = kk[u];
+                  }
+#else
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
                   if (kk[u] != MK_EMPTY) cur[u] = tkey[skc_step(skc_home(hh[u]), step)];
@@ -605,6 +616,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                     cur[u] = atomicCAS(&tkey[skc_step(skc_home(hh[u]), step)], MK_EMPTY, kk[u]);
                     if (cur[u] == MK_EMPTY) cur[u] = kk[u];
                   }
+#endif
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
                   if (kk[u] != MK_EMPTY && cur[u] == kk[u]) {
