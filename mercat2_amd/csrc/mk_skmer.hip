@@ -480,8 +480,8 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
                                                              int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
                                                              int dflags, int canon) {
-  __shared__ u64 tkey[SKC_SLOTS];
-  __shared__ unsigned tcnt[SKC_SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 tkey[SKC_SLOTS];
+  __shared__ __attribute__((aligned(16))) unsigned tcnt[SKC_SLOTS];
   // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
@@ -659,16 +659,26 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           u64 ek[PER];
           unsigned ec[PER];
           unsigned mine = 0, occ = 0;
+          // two neighbouring slots per access: 16-byte key and 8-byte count reads/writes halve the LDS
+          // instructions of this sweep (PER is even: SKC_SLOTS is a multiple of 2 * SKC_THREADS)
+          static_assert(PER % 2 == 0, "emit sweeps slot pairs");
 #pragma unroll
-          for (int q = 0; q < PER; ++q) {
-            const unsigned i = q * SKC_THREADS + threadIdx.x;
-            ek[q] = tkey[i];
-            ec[q] = tcnt[i];
-            tkey[i] = MK_EMPTY;
-            tcnt[i] = 0;
-            occ += ek[q] != MK_EMPTY;
-            if (over || ek[q] == MK_EMPTY || (u64)ec[q] < min_count) ek[q] = MK_EMPTY;
-            mine += ek[q] != MK_EMPTY;
+          for (int q = 0; q < PER; q += 2) {
+            const unsigned i = (q * SKC_THREADS + 2 * threadIdx.x);
+            const ulonglong2 kp = *reinterpret_cast<const ulonglong2*>(&tkey[i]);
+            const uint2 cp = *reinterpret_cast<const uint2*>(&tcnt[i]);
+            *reinterpret_cast<ulonglong2*>(&tkey[i]) = make_ulonglong2(MK_EMPTY, MK_EMPTY);
+            *reinterpret_cast<uint2*>(&tcnt[i]) = make_uint2(0u, 0u);
+            ek[q] = kp.x;
+            ek[q + 1] = kp.y;
+            ec[q] = cp.x;
+            ec[q + 1] = cp.y;
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+              occ += ek[q + z] != MK_EMPTY;
+              if (over || ek[q + z] == MK_EMPTY || (u64)ec[q + z] < min_count) ek[q + z] = MK_EMPTY;
+              mine += ek[q + z] != MK_EMPTY;
+            }
           }
           for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
