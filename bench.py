@@ -177,6 +177,20 @@ def main():
             if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct"):
                 st[key] += val
 
+    # After the timed region: the same kernels alone on the GPU (one context, one pass), so that the
+    # dominant kernel's duration can also be read without the other stream's kernels on its CUs.
+    solo = None
+    if nctx > 1 and rank == 0:
+        c = ctxs[0]
+        c.reset()
+        c.reset_stats()
+        c.set_profiling(True)
+        for a, b in chunks:
+            c.count_device(base_ptr + a, b - a, MIN_COUNT)
+        torch.cuda.synchronize()
+        solo = c.stats()
+        c.set_profiling(False)
+
     red_dev = dev if backend == "nccl" else torch.device("cpu")
     t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     r = torch.tensor([rows], dtype=torch.int64, device=red_dev)
@@ -232,6 +246,12 @@ def main():
                          "stage_frac": stage_achieved / HBM_PEAK_GBS},
             "input_gen_s": gen_s,
         }
+        if solo and solo["n_count"] and solo["ms_count"] > 0:
+            solo_ms = solo["ms_count"] / solo["n_count"]
+            solo_ach = (solo["windows"] - solo["exotic_windows"]) * 16 / solo["n_count"] / (solo_ms * 1e-3) / 1e9
+            # (not `achieved`: that one is measured inside the timed region, where two contexts share the GPU)
+            line["roofline"]["one_context"] = {"ms_per_launch": solo_ms, "achieved": solo_ach, "frac": solo_ach / HBM_PEAK_GBS,
+                                               "note": "same kernel, untimed extra pass with one context"}
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(k, MIN_COUNT)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
