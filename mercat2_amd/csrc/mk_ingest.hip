@@ -169,6 +169,79 @@ static void gz_reader(Ring* R, const uint8_t* file, size_t file_len, const std::
   R->set_total(i);
 }
 
+// BGZF (bgzip): a gzip file of independent members of at most 64 KiB, each announcing its own size in
+// an extra header field ("BC", BSIZE = member bytes - 1), so the member boundaries are known without
+// decoding: consecutive members are grouped into jobs of at most one ring block of text, and any reader
+// thread decodes any job (no history crosses a member).  plan is empty when the file is not BGZF all
+// the way through -- the sequential reader takes it then.
+struct BgzfJob {
+  size_t in_off, in_len;  // members [in_off, in_off + in_len) of the file
+  size_t out_len;         // sum of their ISIZE fields
+};
+static std::vector<BgzfJob> bgzf_plan(const uint8_t* f, size_t n, size_t block) {
+  std::vector<BgzfJob> jobs;
+  size_t p = 0;
+  BgzfJob cur{0, 0, 0};
+  while (p < n) {
+    if (n - p < 18 + 8 || f[p] != 0x1f || f[p + 1] != 0x8b || f[p + 2] != 8 || !(f[p + 3] & 4)) return {};
+    const size_t xlen = (size_t)f[p + 10] | ((size_t)f[p + 11] << 8);
+    if (n - p < 12 + xlen) return {};
+    size_t bsize = 0;
+    for (size_t q = p + 12; q + 4 <= p + 12 + xlen;) {  // sub-fields: SI1 SI2 LEN(2) data
+      const size_t len = (size_t)f[q + 2] | ((size_t)f[q + 3] << 8);
+      if (f[q] == 'B' && f[q + 1] == 'C' && len == 2 && q + 6 <= p + 12 + xlen) bsize = ((size_t)f[q + 4] | ((size_t)f[q + 5] << 8)) + 1;
+      q += 4 + len;
+    }
+    if (bsize < 12 + xlen + 8 + 2 || p + bsize > n) return {};
+    const uint8_t* t = f + p + bsize - 4;
+    const size_t isize = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    if (isize > 65536 || isize > block) return {};
+    if (cur.in_len && cur.out_len + isize > block) {
+      jobs.push_back(cur);
+      cur = BgzfJob{p, 0, 0};
+    }
+    if (!cur.in_len) cur.in_off = p;
+    cur.in_len += bsize;
+    cur.out_len += isize;
+    p += bsize;
+  }
+  if (cur.in_len) jobs.push_back(cur);
+  // (jobs without text -- e.g. the empty end-of-file member on its own -- are kept: they cost nothing)
+  return jobs;
+}
+
+static void bgzf_reader(Ring* R, const uint8_t* file, const std::vector<BgzfJob>* jobs, const std::string* path,
+                        std::atomic<int>* members_out) {
+  for (;;) {
+    const uint64_t i = R->next.fetch_add(1);
+    if (i >= jobs->size()) return;
+    if (!R->wait_writable(i)) return;
+    const BgzfJob& job = (*jobs)[i];
+    uint8_t* const base = R->at(i);
+    MkGzReader rd(file + job.in_off, job.in_len);
+    size_t fill = 0, member_start = 0;
+    bool ok = true;
+    for (;;) {
+      size_t got = 0;
+      const MkGzReader::Status st = rd.fill(base + fill, base + job.out_len, base, &got);
+      fill += got;
+      if (st == MkGzReader::END) break;
+      if (st != MkGzReader::MORE) { ok = false; break; }
+      if (rd.member_ended()) {
+        if (mk_crc32(0, base + member_start, fill - member_start) != rd.member_crc() ||
+            (uint32_t)(fill - member_start) != rd.member_isize()) { ok = false; break; }
+        member_start = fill;
+      } else if (got == 0) { ok = false; break; }  // more text than the trailers announced
+    }
+    if (!ok || fill != job.out_len) {
+      R->fail(MK_ERR_IO, *path + ": corrupt gzip data (BGZF block)");
+      return;
+    }
+    members_out->fetch_add(rd.members());
+    R->publish(i, fill, fill && memchr(base, '\r', fill) != nullptr);
+  }
+}
+
 // ------------------------------------------------------------------------- context workers
 struct Lane {  // one context, its worker thread and the hand-over between dispatcher and worker
   mk_ctx* c = nullptr;
@@ -281,13 +354,25 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   const int lanes_n = chunked ? nctx : 1;
 
   if (threads <= 0) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  if (gz) threads = 1;
   if (hipSetDevice(c0->device) != hipSuccess) { c0->err = "hipSetDevice failed"; close(fd); return MK_ERR_HIP; }
 
   Ring R;
   {
     const char* e = getenv("MK_INGEST_BLOCK");  // (tests shrink the blocks to put every boundary case in reach)
     R.block = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)4 << 20);
+  }
+  void* gz_map = nullptr;
+  std::vector<BgzfJob> bgzf;
+  if (gz) {
+    if (disk) {
+      gz_map = mmap(nullptr, (size_t)disk, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (gz_map == MAP_FAILED) { c0->err = "mmap " + spath + ": " + strerror(errno); close(fd); return MK_ERR_IO; }
+      bgzf = bgzf_plan((const uint8_t*)gz_map, (size_t)disk, R.block);
+      (void)madvise(gz_map, (size_t)disk, bgzf.empty() ? MADV_SEQUENTIAL : MADV_WILLNEED);
+    }
+    if (bgzf.empty()) threads = 1;  // one DEFLATE stream can only be decoded front to back
+  }
+  {
     R.slots = 2 * threads + 4;
     // gzip: the decoder reads up to 32 KiB back across the blocks, which must therefore still be in the ring
     if (gz && (size_t)R.slots * R.block < 2 * MK_GZ_WINDOW + 2 * R.block)
@@ -300,6 +385,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
       const hipError_t he = hipHostMalloc(&c0->ingest_ring, bytes, hipHostMallocDefault);
       if (he != hipSuccess) {
         c0->err = "hipHostMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(he);
+        if (gz_map) (void)munmap(gz_map, (size_t)disk);
         close(fd);
         return MK_ERR_NOMEM;
       }
@@ -337,21 +423,16 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = MK_ERR_HIP;
 
   int members = 0;
-  void* gz_map = nullptr;
+  std::atomic<int> bgzf_members{0};
   std::vector<std::thread> readers;
   uint64_t nblocks = 0;
   if (rc == MK_OK) {
-    if (gz) {
-      if (disk) {
-        gz_map = mmap(nullptr, (size_t)disk, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (gz_map == MAP_FAILED) {
-          gz_map = nullptr;
-          R.fail(MK_ERR_IO, "mmap " + spath + ": " + strerror(errno));
-        } else {
-          (void)madvise(gz_map, (size_t)disk, MADV_SEQUENTIAL);
-        }
-      }
-      if (gz_map || !disk) readers.emplace_back(gz_reader, &R, (const uint8_t*)gz_map, (size_t)disk, &spath, &members);
+    if (gz && !bgzf.empty()) {
+      R.total = bgzf.size();
+      for (int t = 0; t < threads && (size_t)t < bgzf.size(); ++t)
+        readers.emplace_back(bgzf_reader, &R, (const uint8_t*)gz_map, &bgzf, &spath, &bgzf_members);
+    } else if (gz) {
+      readers.emplace_back(gz_reader, &R, (const uint8_t*)gz_map, (size_t)disk, &spath, &members);
     } else {
       nblocks = (disk + R.block - 1) / R.block;
       R.total = nblocks;
@@ -440,7 +521,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     st->chunks = D.chunks;
     st->gz = gz ? 1 : 0;
     st->chunked = chunked ? 1 : 0;
-    st->members = members;
+    st->members = members + bgzf_members.load();
     st->threads = threads;
     st->contexts = lanes_n;
     st->s_wait_io = s_wait_io;

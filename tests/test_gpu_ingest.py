@@ -206,3 +206,53 @@ def test_cli_writes_the_combined_table(tmp_path, capsys):
     want = "k-mer\t" + "\t".join(cols) + "\n" + "".join(
         key + "\t" + "\t".join(str(tables[c].get(key, 0)) for c in cols) + "\n" for key in keys)
     assert (out / "combined_Nucleotide.tsv").read_text() == want
+
+
+def _bgzf(data: bytes, piece: int = 60_000) -> bytes:
+    """A BGZF file (bgzip's format): independent gzip members of <= 64 KiB with a 'BC' extra field."""
+    import struct
+    import zlib
+    out = []
+    pieces = [data[i:i + piece] for i in range(0, len(data), piece)] + [b""]      # + the empty end-of-file member
+    for p in pieces:
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(p) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body +
+                   struct.pack("<II", zlib.crc32(p), len(p)))
+    return b"".join(out)
+
+
+def test_count_file_bgzf_blocks_are_decoded_in_parallel(tmp_path):
+    rng = random.Random(21)
+    text = _reads(rng, 12_000, wrap=70)
+    blob = _bgzf(text)
+    assert gzip.decompress(blob) == text
+    path = tmp_path / "reads.fna.gz"
+    path.write_bytes(blob)
+    nmembers = (len(text) + 59_999) // 60_000 + 1
+    for chunk_bytes, nctx in ((0, 1), (len(blob) // 3, 2)):
+        want, nchunks = _oracle_sample(text, 21, 2, chunk_bytes, len(blob))
+        ctxs = [native.Counter(21, native.ALPHABET_NT2) for _ in range(nctx)]
+        try:
+            st = native.count_file(ctxs, path, chunk_bytes, 2, threads=4)
+            assert ctxs[0].to_dict() == want
+            assert st["gz"] == 1 and st["threads"] == 4 and st["members"] == nmembers and st["text_bytes"] == len(text)
+            assert st["chunks"] == nchunks
+        finally:
+            for x in ctxs:
+                x.close()
+    # a damaged block is reported, whichever thread meets it
+    bad = bytearray(blob)
+    bad[len(bad) // 2] ^= 0xFF
+    (tmp_path / "bad.fna.gz").write_bytes(bytes(bad))
+    with native.Counter(21, native.ALPHABET_NT2) as ctx:
+        with pytest.raises(native.MercatHipError, match="gzip"):
+            native.count_file([ctx], tmp_path / "bad.fna.gz", 0, 2, threads=4)
+    # BGZF blocks followed by an ordinary gzip member: not BGZF all the way, so the front-to-back reader takes it
+    mixed = blob + gzip.compress(b">tail\nACGTACGTACGTACGTACGTACGTAC\n")
+    (tmp_path / "mixed.fna.gz").write_bytes(mixed)
+    with native.Counter(21, native.ALPHABET_NT2) as ctx:
+        st = native.count_file([ctx], tmp_path / "mixed.fna.gz", 0, 2, threads=4)
+        assert st["threads"] == 1 and st["members"] == nmembers + 1
+        assert ctx.to_dict() == cpu_ref.count_text(text + b">tail\nACGTACGTACGTACGTACGTACGTAC\n", 21, 2)

@@ -4,6 +4,22 @@ import os, sys, time, tempfile
 sys.path.insert(0, ".")
 from mercat2_amd import native, harness
 
+def _bgzf_member(p):
+    import struct, zlib
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    body = c.compress(p) + c.flush()
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", 12 + 6 + len(body) + 8 - 1) + body +
+            struct.pack("<II", zlib.crc32(p), len(p)))
+
+
+def _bgzf_span(span):
+    path, a, b = span
+    with open(path, "rb") as f:
+        f.seek(a)
+        data = f.read(b - a)
+    return b"".join(_bgzf_member(data[i:i + 65280]) for i in range(0, len(data), 65280))
+
+
 def main():
     reads = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 31
@@ -22,8 +38,22 @@ def main():
         subprocess.run(["gzip", "-1", "-k", path], check=True)
         gz = path + ".gz"
         print("gzip -1 -> %.2f GB in %.1f s" % (os.path.getsize(gz) / 1e9, time.perf_counter() - t0))
-    for f in [path] + ([gz] if gz else []):
-        for streams, threads in (((1, 0), (2, 0), (2, 2), (2, 16)) if not f.endswith('.gz') else ((2, 0), (2, 0), (2, 0))):
+    bg = None
+    if "--bgzf" in sys.argv:
+        from multiprocessing import Pool
+        t0 = time.perf_counter()
+        size = os.path.getsize(path)
+        spans = [(path, a, min(a + (64 << 20), size)) for a in range(0, size, 64 << 20)]
+        with Pool(16) as pool:
+            parts = pool.map(_bgzf_span, spans)
+        bg = os.path.join(d, "S2_bgzf.fna.gz")
+        with open(bg, "wb") as w:
+            for part in parts:
+                w.write(part)
+            w.write(_bgzf_member(b""))
+        print("bgzf -> %.2f GB in %.1f s" % (os.path.getsize(bg) / 1e9, time.perf_counter() - t0))
+    for f in [path] + ([gz] if gz else []) + ([bg] if bg else []):
+        for streams, threads in (((1, 0), (2, 0), (2, 2), (2, 16)) if not f.endswith('.gz') else (((2, 0), (2, 0), (2, 0)) if 'bgzf' not in f else ((2, 1), (2, 4), (2, 8), (2, 16)))):
             for rep in range(2):
                 out = os.path.join(d, "S2_counts_%d.tsv" % streams)
                 st = {}
