@@ -121,7 +121,8 @@ typedef struct mk_file_stats_t {
  * survivors to the running table of ctxs[0].  With nctx > 1 (same device, alphabet, k) the chunks
  * are dealt to the contexts in turn and counted concurrently with the reading; the other
  * contexts' tables are added into ctxs[0] and reset before the call returns.  threads = reader
- * threads for plain files (<= 0: pick); a gzip stream is inflated by one thread.  st may be NULL. */
+ * threads (<= 0: pick): plain files are read, BGZF blocks and -- from 16 MiB on -- ordinary gzip
+ * streams are decoded by that many threads; 1 decodes a gzip stream front to back.  st may be NULL. */
 int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, uint64_t chunk_bytes, uint64_t min_count,
                   int threads, mk_file_stats_t* st);
 
@@ -196,6 +197,10 @@ int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t blo
  * A self-check for tests (against zlib): out must hold the whole text (cap bytes).
  * MK_ERR_IO: corrupt or not gzip, MK_ERR_RANGE: truncated, MK_ERR_NOMEM: cap too small. */
 int mk_gunzip(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, size_t block, size_t* written, int* members);
+/* The same through the parallel decoder (csrc/mk_pgunzip.h): `threads` pieces of `piece_bytes` compressed
+ * bytes are decoded at once, each from a block start found by search, and stitched together. */
+int mk_gunzip_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, int threads, size_t piece_bytes,
+                       size_t* written, int* members);
 /* zlib's crc32(seed, p, n) as the gzip reader computes it (carry-less multiplies; csrc/mk_crc32.h). */
 uint32_t mk_crc32_of(const uint8_t* p, size_t n, uint32_t seed);
 /* Deterministic synthetic reads: genome of `genome_len` iid ACGT from

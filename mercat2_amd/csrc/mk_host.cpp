@@ -9,6 +9,7 @@
 #include "mk_cutscan.h"
 #include "mk_inflate.h"
 #include "mk_crc32.h"
+#include "mk_pgunzip.h"
 
 // ---------------------------------------------------------------------------- virtual Chunker
 // Restates Chunker.stream_delim (lib/mercat2_Chunker.py:39-59) without writing chunk files:
@@ -111,6 +112,28 @@ extern "C" int mk_gunzip(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, 
     } else if (got == 0 && room == 0) {
       return MK_ERR_NOMEM;  // cap too small
     }
+  }
+  *written = at;
+  if (members) *members = rd.members();
+  return MK_OK;
+}
+
+// The same text through the parallel decoder (mk_pgunzip.h): `threads` pieces of `piece_bytes` compressed
+// bytes per round.  A self-check for tests.
+extern "C" int mk_gunzip_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, int threads, size_t piece_bytes,
+                                  size_t* written, int* members) {
+  if (!written || (n && !gz)) return MK_ERR_ARG;
+  MkParallelGunzip rd(gz, n, threads, piece_bytes);
+  size_t at = 0;
+  for (;;) {
+    const uint8_t* part = nullptr;
+    size_t len = 0;
+    const MkParallelGunzip::Status s = rd.next(&part, &len);
+    if (s == MkParallelGunzip::END) break;
+    if (s != MkParallelGunzip::MORE) return s == MkParallelGunzip::TRUNCATED ? MK_ERR_RANGE : MK_ERR_IO;
+    if (len > cap - at) return MK_ERR_NOMEM;
+    memcpy(out + at, part, len);
+    at += len;
   }
   *written = at;
   if (members) *members = rd.members();

@@ -17,13 +17,20 @@
 #include <stdint.h>
 #include <string.h>
 
-class MkInflate {
+// OutT is the output element: uint8_t for text, uint16_t for the speculative decoding of a stream whose
+// first 32 KiB of history are not known yet (MkParallelGunzip below: elements >= 256 name a position in
+// that unknown window, and copying them around like any other element is all a match ever does).
+template <class OutT>
+class MkInflateT {
  public:
-  enum Status { OUT_FULL = 0, STREAM_END = 1, BAD_DATA = -1, TRUNCATED = -2 };
+  enum Status { OUT_FULL = 0, STREAM_END = 1, STOPPED = 2, BAD_DATA = -1, TRUNCATED = -2 };
 
   // Start a raw DEFLATE stream at `in` (in_end: end of the readable input).
-  void reset(const uint8_t* in, const uint8_t* in_end) {
-    in_ = in;
+  void reset(const uint8_t* in, const uint8_t* in_end) { reset_at_bit(in, in_end, 0); }
+  // Start at bit `bitpos` of [base, in_end): a block header is expected there.
+  void reset_at_bit(const uint8_t* base, const uint8_t* in_end, uint64_t bitpos) {
+    base_ = base;
+    in_ = base + (bitpos >> 3);
     in_end_ = in_end;
     bitbuf_ = 0;
     bitcnt_ = 0;
@@ -31,14 +38,27 @@ class MkInflate {
     last_ = false;
     mlen_ = 0;
     stored_left_ = 0;
+    stop_bit_ = ~0ull;
+    if (bitpos & 7) {
+      refill_safe();
+      if (bitcnt_ >= (int)(bitpos & 7)) drop((int)(bitpos & 7));
+    }
   }
+  // Bit offset (from the base given to reset) of the next unread bit.
+  uint64_t bit_position() const { return (uint64_t)(in_ - base_) * 8 - (uint64_t)bitcnt_; }
+  // run() returns STOPPED instead of reading a block header at (or, having missed it, beyond) this bit.
+  void set_stop_bit(uint64_t bit) { stop_bit_ = bit; }
+  // Accept only what a compressor writes: complete Huffman codes (strict), for the search for a block start.
+  void set_strict(bool on) { strict_ = on; }
+  bool at_block_header() const { return state_ == ST_BLOCK_HEADER; }
+  bool final_block_seen() const { return last_; }
   // First input byte not yet consumed once STREAM_END was returned (the stream's padding bits dropped).
   const uint8_t* input_pos() const { return in_ - (bitcnt_ >> 3); }
 
   // Decode into [out, out_end).  `window` is the lowest address a match may reach back to (the 32 KiB
   // before `out` belong to the same stream when they lie at or above it).  *produced = bytes written.
-  Status run(uint8_t* out, uint8_t* out_end, const uint8_t* window, size_t* produced) {
-    uint8_t* const out0 = out;
+  Status run(OutT* out, OutT* out_end, const OutT* window, size_t* produced) {
+    OutT* const out0 = out;
     Status rc = OUT_FULL;
     for (;;) {
       if (state_ == ST_MATCH) {  // a match cut by the end of the previous output block
@@ -48,6 +68,7 @@ class MkInflate {
       }
       if (state_ == ST_BLOCK_HEADER) {
         if (last_) { rc = STREAM_END; break; }
+        if (bit_position() >= stop_bit_) { rc = STOPPED; break; }
         if (!need(3)) { rc = TRUNCATED; break; }
         last_ = take(1) != 0;
         const unsigned type = take(2);
@@ -78,7 +99,8 @@ class MkInflate {
         size_t n = stored_left_;
         if ((size_t)(in_end_ - in_) < n) { rc = TRUNCATED; break; }
         if ((size_t)(out_end - out) < n) n = (size_t)(out_end - out);
-        memcpy(out, in_, n);
+        if (sizeof(OutT) == 1) memcpy(out, in_, n);
+        else for (size_t q = 0; q < n; ++q) out[q] = (OutT)in_[q];
         out += n;
         in_ += n;
         stored_left_ -= (unsigned)n;
@@ -154,7 +176,7 @@ class MkInflate {
   // length byte.  Returns false for an over-subscribed set; an incomplete set leaves zero entries.
   template <class EntryOf>
   static bool build(const uint8_t* lens, int nsyms, int primary_bits, uint32_t* table, int table_cap, uint32_t sub_flag,
-                    EntryOf entry_of) {
+                    EntryOf entry_of, bool* complete = nullptr, int* used_codes = nullptr) {
     int count[16] = {0};
     for (int s = 0; s < nsyms; ++s) count[lens[s]]++;
     count[0] = 0;
@@ -165,6 +187,8 @@ class MkInflate {
       left = (left << 1) - count[l];
       if (left < 0) return false;
     }
+    if (complete) *complete = left == 0;
+    if (used_codes) { *used_codes = 0; for (int l = 1; l <= 15; ++l) *used_codes += count[l]; }
     unsigned next[16];
     {
       unsigned code = 0;
@@ -276,7 +300,9 @@ class MkInflate {
       cl[order[i]] = (uint8_t)take(3);
     }
     uint32_t ct[128];
-    if (!build(cl, 19, 7, ct, 128, 0u, [](int s) { return (uint32_t)s << 16; })) return -1;
+    bool full = false;
+    if (!build(cl, 19, 7, ct, 128, 0u, [](int s) { return (uint32_t)s << 16; }, &full)) return -1;
+    if (strict_ && !full) return -1;
     uint8_t lens[286 + 30 + 138];
     int n = 0;
     const int total = hlit + hdist;
@@ -313,15 +339,19 @@ class MkInflate {
       }
     }
     if (!lens[256]) return -1;  // no end-of-block code
-    if (!build(lens, hlit, LBITS, lt_, LT_CAP, F_SUB, litlen_entry)) return -1;
-    if (!build(lens + hlit, hdist, DBITS, dt_, DT_CAP, F_DSUB, dist_entry)) return -1;
+    int ndist = 0;
+    if (!build(lens, hlit, LBITS, lt_, LT_CAP, F_SUB, litlen_entry, &full)) return -1;
+    if (strict_ && !full) return -1;
+    if (!build(lens + hlit, hdist, DBITS, dt_, DT_CAP, F_DSUB, dist_entry, &full, &ndist)) return -1;
+    if (strict_ && !full && ndist > 1) return -1;  // (zlib writes a lone distance code as an incomplete set)
     pair_literals();
     return 0;
   }
 
   // ---- the symbol loop -------------------------------------------------------------------
-  int huff(uint8_t*& out_ref, uint8_t* out_end, const uint8_t* window) {
-    uint8_t* out = out_ref;
+  int huff(OutT*& out_ref, OutT* out_end, const OutT* window) {
+    OutT* out = out_ref;
+    constexpr int E = 8 / (int)sizeof(OutT);  // elements per 8-byte copy
     int rc = 0;
     // fast part: room for one whole step without checks (3 literals or a 258-byte match copied in
     // 8-byte pieces; 8 input bytes per refill, two refills per step at most)
@@ -335,20 +365,20 @@ class MkInflate {
       if (e & F_LIT) {
         // up to three entries (one or two literals each) from one refill: <= 33 of the >= 56 bits
         drop((int)(e & 0xFF));
-        out[0] = (uint8_t)(e >> 16);
-        out[1] = (uint8_t)(e >> 8);
+        out[0] = (OutT)(uint8_t)(e >> 16);
+        out[1] = (OutT)(uint8_t)(e >> 8);
         out += 1 + ((e >> 28) & 1);
         e = lt_[bitbuf_ & ((1u << LBITS) - 1)];
         if ((e & (F_LIT | F_SUB)) == F_LIT) {
           drop((int)(e & 0xFF));
-          out[0] = (uint8_t)(e >> 16);
-          out[1] = (uint8_t)(e >> 8);
+          out[0] = (OutT)(uint8_t)(e >> 16);
+          out[1] = (OutT)(uint8_t)(e >> 8);
           out += 1 + ((e >> 28) & 1);
           e = lt_[bitbuf_ & ((1u << LBITS) - 1)];
           if ((e & (F_LIT | F_SUB)) == F_LIT) {
             drop((int)(e & 0xFF));
-            out[0] = (uint8_t)(e >> 16);
-            out[1] = (uint8_t)(e >> 8);
+            out[0] = (OutT)(uint8_t)(e >> 16);
+            out[1] = (OutT)(uint8_t)(e >> 8);
             out += 1 + ((e >> 28) & 1);
           }
         }
@@ -374,13 +404,13 @@ class MkInflate {
       const unsigned dist = ((d >> 16) & 0x7FFF) + (unsigned)(bitbuf_ & ((1u << dx) - 1));
       drop(dx);
       if ((size_t)(out - window) < dist) { rc = H_BAD; break; }
-      const uint8_t* src = out - dist;
-      uint8_t* const end = out + len;
-      if (dist >= 8) {
+      const OutT* src = out - dist;
+      OutT* const end = out + len;
+      if (dist >= (unsigned)E) {
         do {
           memcpy(out, src, 8);
-          out += 8;
-          src += 8;
+          out += E;
+          src += E;
         } while (out < end);
       } else {
         do { *out++ = *src++; } while (out < end);
@@ -402,7 +432,7 @@ class MkInflate {
       // (an end-of-block code needs no room: a text that fills its buffer exactly still ends cleanly)
       if (!(e & F_EOB) && out == out_end) { rc = H_OUT_FULL; break; }
       drop(used + cl);
-      if (e & F_LIT) { *out++ = (uint8_t)(e >> 16); continue; }
+      if (e & F_LIT) { *out++ = (OutT)(uint8_t)(e >> 16); continue; }
       if (e & F_EOB) { rc = H_BLOCK_END; break; }
       const int lx = (int)((e >> 8) & 31);
       if (bitcnt_ < lx) refill_safe();
@@ -435,8 +465,11 @@ class MkInflate {
   }
 
   static constexpr int LT_CAP = (1 << LBITS) + 1024, DT_CAP = (1 << DBITS) + 512;
+  const uint8_t* base_ = nullptr;
   const uint8_t* in_ = nullptr;
   const uint8_t* in_end_ = nullptr;
+  uint64_t stop_bit_ = ~0ull;
+  bool strict_ = false;
   uint64_t bitbuf_ = 0;
   int bitcnt_ = 0;
   int state_ = ST_BLOCK_HEADER;
@@ -448,12 +481,41 @@ class MkInflate {
   uint32_t mark_[(1 << LBITS) / 32] = {0};
 };
 
+using MkInflate = MkInflateT<uint8_t>;
+
 // gzip member framing around MkInflate over a whole file in memory: header, deflate stream, CRC-32 and
 // ISIZE trailer, any number of members, zero padding between/after them skipped (as gzip.py does).
 class MkGzReader {
  public:
   enum Status { MORE = 0, END = 1, BAD_DATA = -1, TRUNCATED = -2, BAD_HEADER = -3 };
   MkGzReader(const uint8_t* data, size_t n) : p_(data), end_(data + n) {}
+  // Length of the gzip member header at p: 0 ok (*len set), 1 truncated, -1 not a gzip member.
+  static int header_length(const uint8_t* p, const uint8_t* end, size_t* len) {
+    if (end - p < 10) return (end - p >= 2 && !(p[0] == 0x1f && p[1] == 0x8b)) ? -1 : 1;
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xE0)) return -1;
+    const unsigned flg = p[3];
+    const uint8_t* q = p + 10;
+    if (flg & 4) {
+      if (end - q < 2) return 1;
+      const size_t xlen = (size_t)q[0] | ((size_t)q[1] << 8);
+      q += 2;
+      if ((size_t)(end - q) < xlen) return 1;
+      q += xlen;
+    }
+    for (unsigned bit = 8; bit <= 16; bit <<= 1) {  // FNAME, FCOMMENT: zero-terminated
+      if (flg & bit) {
+        const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end - q));
+        if (!z) return 1;
+        q = z + 1;
+      }
+    }
+    if (flg & 2) {
+      if (end - q < 2) return 1;
+      q += 2;
+    }
+    *len = (size_t)(q - p);
+    return 0;
+  }
   int members() const { return members_; }
   // The trailer of the member that ended inside the last fill() (valid while member_ended()):
   bool member_ended() const { return ended_; }
@@ -490,30 +552,10 @@ class MkGzReader {
 
  private:
   int header() {  // 0 ok, 1 truncated, -1 not gzip
-    if (end_ - p_ < 10) return (end_ - p_ >= 2 && !(p_[0] == 0x1f && p_[1] == 0x8b)) ? -1 : 1;
-    if (p_[0] != 0x1f || p_[1] != 0x8b || p_[2] != 8 || (p_[3] & 0xE0)) return -1;
-    const unsigned flg = p_[3];
-    const uint8_t* q = p_ + 10;
-    if (flg & 4) {
-      if (end_ - q < 2) return 1;
-      const size_t xlen = (size_t)q[0] | ((size_t)q[1] << 8);
-      q += 2;
-      if ((size_t)(end_ - q) < xlen) return 1;
-      q += xlen;
-    }
-    for (unsigned bit = 8; bit <= 16; bit <<= 1) {  // FNAME, FCOMMENT: zero-terminated
-      if (flg & bit) {
-        const uint8_t* z = (const uint8_t*)memchr(q, 0, (size_t)(end_ - q));
-        if (!z) return 1;
-        q = z + 1;
-      }
-    }
-    if (flg & 2) {
-      if (end_ - q < 2) return 1;
-      q += 2;
-    }
-    p_ = q;
-    return 0;
+    size_t len = 0;
+    const int rc = header_length(p_, end_, &len);
+    if (rc == 0) p_ += len;
+    return rc;
   }
   const uint8_t* p_;
   const uint8_t* end_;

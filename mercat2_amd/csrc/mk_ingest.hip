@@ -23,6 +23,7 @@
 #include "mk_cutscan.h"
 #include "mk_inflate.h"
 #include "mk_crc32.h"
+#include "mk_pgunzip.h"
 #include <sys/mman.h>
 
 namespace {
@@ -165,6 +166,45 @@ static void gz_reader(Ring* R, const uint8_t* file, size_t file_len, const std::
       ++i;
     }
   }
+  *members_out = rd.members();
+  R->set_total(i);
+}
+
+// The same file through several threads (mk_pgunzip.h: block starts found by search, unknown history
+// carried as place holders, every piece verified against the one before it).  This thread runs the
+// rounds and copies their text into the ring.
+static void gz_parallel_reader(Ring* R, const uint8_t* file, size_t file_len, const std::string* path, int* members_out,
+                               int threads) {
+  MkParallelGunzip rd(file, file_len, threads, (size_t)4 << 20);
+  uint64_t i = 0;
+  double s_copy = 0;
+  for (;;) {
+    const uint8_t* text = nullptr;
+    size_t n = 0;
+    const MkParallelGunzip::Status st = rd.next(&text, &n);
+    if (st == MkParallelGunzip::END) break;
+    if (st != MkParallelGunzip::MORE) {
+      R->fail(MK_ERR_IO, *path + (st == MkParallelGunzip::TRUNCATED ? ": gzip stream is truncated"
+                                  : st == MkParallelGunzip::BAD_HEADER ? ": not a gzip file (or data after the last member)"
+                                  : st == MkParallelGunzip::BAD_CRC  ? ": gzip CRC check failed"
+                                                                     : ": corrupt gzip data"));
+      break;
+    }
+    bool stop = false;
+    const auto t0 = Clock::now();
+    for (size_t off = 0; off < n && !stop; off += R->block) {
+      const size_t m = n - off < R->block ? n - off : R->block;
+      if (!R->wait_writable(i)) { stop = true; break; }
+      memcpy(R->at(i), text + off, m);
+      R->publish(i, m, memchr(text + off, '\r', m) != nullptr);
+      ++i;
+    }
+    s_copy += seconds_since(t0);
+    if (stop) break;
+  }
+  if (getenv("MK_VERBOSE"))
+    fprintf(stderr, "[mk] parallel gunzip: find %.3f s, decode %.3f s, stitch %.3f s, copy+wait %.3f s; pieces %zu started, %zu kept\n",
+            rd.engine().s_find, rd.engine().s_decode, rd.engine().s_stitch, s_copy, rd.engine().pieces_started, rd.engine().pieces_kept);
   *members_out = rd.members();
   R->set_total(i);
 }
@@ -353,7 +393,8 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   const bool chunked = chunk_bytes > 0 && disk >= chunk_bytes;
   const int lanes_n = chunked ? nctx : 1;
 
-  if (threads <= 0) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  const bool auto_threads = threads <= 0;
+  if (auto_threads) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   if (hipSetDevice(c0->device) != hipSuccess) { c0->err = "hipSetDevice failed"; close(fd); return MK_ERR_HIP; }
 
   Ring R;
@@ -362,6 +403,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     R.block = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)4 << 20);
   }
   void* gz_map = nullptr;
+  bool gz_parallel = false;
   std::vector<BgzfJob> bgzf;
   if (gz) {
     if (disk) {
@@ -370,7 +412,13 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
       bgzf = bgzf_plan((const uint8_t*)gz_map, (size_t)disk, R.block);
       (void)madvise(gz_map, (size_t)disk, bgzf.empty() ? MADV_SEQUENTIAL : MADV_WILLNEED);
     }
-    if (bgzf.empty()) threads = 1;  // one DEFLATE stream can only be decoded front to back
+    // one DEFLATE stream: several threads pay off from a few pieces on (MK_GZ_SERIAL=1: always front to back)
+    // (decoding scales further than reading: measured 1.1 s with 8 threads, 0.75 s with 16 on the 1.6 GB S2 file)
+    if (auto_threads) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (bgzf.empty()) {
+      gz_parallel = threads > 1 && disk >= ((size_t)16 << 20) && !getenv("MK_GZ_SERIAL");
+      if (!gz_parallel) threads = 1;
+    }
   }
   {
     R.slots = 2 * threads + 4;
@@ -431,6 +479,8 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
       R.total = bgzf.size();
       for (int t = 0; t < threads && (size_t)t < bgzf.size(); ++t)
         readers.emplace_back(bgzf_reader, &R, (const uint8_t*)gz_map, &bgzf, &spath, &bgzf_members);
+    } else if (gz && gz_parallel) {
+      readers.emplace_back(gz_parallel_reader, &R, (const uint8_t*)gz_map, (size_t)disk, &spath, &members, threads);
     } else if (gz) {
       readers.emplace_back(gz_reader, &R, (const uint8_t*)gz_map, (size_t)disk, &spath, &members);
     } else {

@@ -1,0 +1,348 @@
+// mk_pgunzip.h -- one DEFLATE stream decoded by several threads (host code).
+//
+// A plain gzip file is a single bit stream with no index: block k can only be located by decoding
+// blocks 0..k-1, and its matches reach into the 32 KiB of text before it.  Both obstacles have a known
+// way around (Kerbiriou & Chikhi, "Parallel decompression of gzip-compressed files and random access to
+// DNA sequences", 2019), restated here for the reader's decoder (mk_inflate.h):
+//   1. The compressed bytes are cut at arbitrary places.  From each cut a thread tries bit offset after
+//      bit offset until a dynamic-Huffman block header parses under strict rules (complete code sets, an
+//      end-of-block code) and 16 K symbols decode after it without an error and with text-like literals.
+//      For random bits that is practically impossible, for a true block start it always succeeds.
+//   2. Each thread decodes from its start to the next thread's start into 16-bit elements, the 32 KiB
+//      before its start filled with the values 256 + position: a match that reaches into the unknown
+//      history just copies those place holders along.  When the text before a piece is known, every
+//      element >= 256 is replaced by the byte it names.
+// Nothing rests on the search having been right: the piece before (decoded from a verified start, hence
+// the true stream) must arrive at a block header at exactly the bit the next piece started from; if it
+// does not, that piece and everything after it is dropped and decoding resumes from the last verified
+// block header.  The gzip CRC-32 is still checked by the caller.
+#ifndef MK_PGUNZIP_H
+#define MK_PGUNZIP_H
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <memory>
+#include <thread>
+#include <vector>
+
+#include "mk_crc32.h"
+#include "mk_inflate.h"
+
+// Growable array without value-initialisation (std::vector would zero hundreds of megabytes per round).
+template <class T>
+struct MkRawBuf {
+  T* p = nullptr;
+  size_t cap = 0;
+  MkRawBuf() = default;
+  MkRawBuf(const MkRawBuf&) = delete;
+  MkRawBuf& operator=(const MkRawBuf&) = delete;
+  ~MkRawBuf() { free(p); }
+  bool reserve(size_t n) {  // keeps the content
+    if (n <= cap) return true;
+    T* q = (T*)realloc(p, n * sizeof(T));
+    if (!q) return false;
+    p = q;
+    cap = n;
+    return true;
+  }
+};
+
+class MkParallelInflate {
+ public:
+  static constexpr size_t WINDOW = 32768;
+  enum Result { MORE = 0, STREAM_END = 1, BAD_DATA = -1, TRUNCATED = -2 };
+
+  double s_find = 0, s_decode = 0, s_stitch = 0;  // seconds per phase, summed over the rounds
+  size_t pieces_started = 0, pieces_kept = 0;
+
+  MkParallelInflate(int threads, size_t piece_bytes) : threads_(threads < 1 ? 1 : threads), piece_(piece_bytes < 4096 ? 4096 : piece_bytes) {}
+
+  // Decode from bit `start_bit` of [base, end) -- a verified block header -- whose preceding text ends
+  // with history[0..history_len) (up to 32 KiB).  One round: up to `threads` pieces of `piece_bytes`
+  // compressed bytes.  The text is appended to out; *next_bit is where the next round starts (a block
+  // header) or, at STREAM_END, the bit after the final block.
+  Result round(const uint8_t* base, const uint8_t* end, uint64_t start_bit, const uint8_t* history, size_t history_len,
+               const uint8_t** text, size_t* text_len, uint64_t* next_bit) {
+    *text = nullptr;
+    *text_len = 0;
+    const uint64_t end_bit = (uint64_t)(end - base) * 8;
+    const auto t_a = std::chrono::steady_clock::now();
+    // ---- 1. piece starts: the verified one, then the first plausible block header after every cut
+    std::vector<uint64_t> start(1, start_bit);
+    {
+      std::vector<uint64_t> found((size_t)threads_, NONE);
+      std::vector<std::thread> th;
+      for (int t = 1; t < threads_; ++t) {
+        const uint64_t from = start_bit + (uint64_t)t * piece_ * 8, to = from + (uint64_t)piece_ * 8;
+        if (from + 64 >= end_bit) break;
+        th.emplace_back([=, &found] { found[(size_t)t] = find_block(base, end, from, to < end_bit ? to : end_bit); });
+      }
+      for (auto& x : th) x.join();
+      for (int t = 1; t < threads_; ++t)
+        if (found[(size_t)t] != NONE && found[(size_t)t] > start.back()) start.push_back(found[(size_t)t]);
+    }
+    const size_t n = start.size();
+    const auto t_b = std::chrono::steady_clock::now();
+    // ---- 2. decode every piece up to the start of the next one (buffers are kept from round to round)
+    if (piece_buf_.size() < n) {
+      const size_t old = piece_buf_.size();
+      piece_buf_.resize(n);
+      for (size_t t = old; t < n; ++t) piece_buf_[t].reset(new Piece);
+    }
+    auto piece = [&](size_t t) -> Piece& { return *piece_buf_[t]; };
+    {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < n; ++t) {
+        const uint64_t stop = t + 1 < n ? start[t + 1] : start_bit + (uint64_t)threads_ * piece_ * 8;  // (last: the round's nominal end)
+        Piece* pc = piece_buf_[t].get();
+        const uint64_t from = start[t];
+        th.emplace_back([=] {
+          if (t == 0) decode_known(base, end, from, stop, history, history_len, *pc);
+          else decode_unknown(base, end, from, stop, *pc);
+        });
+      }
+      for (auto& x : th) x.join();
+    }
+    const auto t_c = std::chrono::steady_clock::now();
+    // ---- 3. keep the pieces that follow on from a verified one
+    size_t good = 1;
+    if (piece(0).status < 0) return (Result)piece(0).status;
+    while (good < n && piece(good - 1).status == MkInflate::STOPPED && piece(good - 1).end_bit == start[good] && piece(good).status >= 0) ++good;
+    // ---- 4. resolve the place holders: the window before each piece first (a chain), then the pieces at once
+    std::vector<size_t> off(good + 1, 0);
+    for (size_t t = 0; t < good; ++t) off[t + 1] = off[t] + piece(t).len;
+    if (good == 1) {  // nothing to stitch: hand out the first piece's buffer as it is
+      *text = piece(0).text8.p + WINDOW;
+      *text_len = piece(0).len;
+      *next_bit = piece(0).end_bit;
+      return piece(0).status == MkInflate::STREAM_END ? STREAM_END : piece(0).status == MkInflate::STOPPED ? MORE : (Result)piece(0).status;
+    }
+    if (!out_.reserve(off[good] + 8)) return BAD_DATA;
+    std::vector<std::vector<uint8_t>> win(good);  // win[t]: the WINDOW bytes before piece t (right-aligned)
+    for (size_t t = 1; t < good; ++t) {
+      win[t].assign(WINDOW, 0);
+      // the last WINDOW bytes of (window before piece t-1) ++ (piece t-1)
+      const size_t have = piece(t - 1).len;
+      if (t == 1) {
+        const uint8_t* p0 = piece(0).text8.p;  // [history window][text]
+        memcpy(win[1].data(), p0 + have, WINDOW);   // == last WINDOW bytes of that buffer
+      } else if (have >= WINDOW) {
+        const uint16_t* s = piece(t - 1).text16.p + WINDOW + have - WINDOW;
+        for (size_t i = 0; i < WINDOW; ++i) win[t][i] = s[i] < 256 ? (uint8_t)s[i] : win[t - 1][s[i] - 256];
+      } else {
+        memcpy(win[t].data(), win[t - 1].data() + have, WINDOW - have);
+        const uint16_t* s = piece(t - 1).text16.p + WINDOW;
+        for (size_t i = 0; i < have; ++i) win[t][WINDOW - have + i] = s[i] < 256 ? (uint8_t)s[i] : win[t - 1][s[i] - 256];
+      }
+    }
+    {
+      std::vector<std::thread> th;
+      for (size_t t = 0; t < good; ++t) {
+        const Piece* pc = piece_buf_[t].get();
+        uint8_t* d = out_.p + off[t];
+        const uint8_t* w = t ? win[t].data() : nullptr;
+        th.emplace_back([=] {
+          const size_t m = pc->len;
+          if (!w) { memcpy(d, pc->text8.p + WINDOW, m); return; }
+          const uint16_t* s = pc->text16.p + WINDOW;
+          for (size_t i = 0; i < m; ++i) d[i] = s[i] < 256 ? (uint8_t)s[i] : w[s[i] - 256];
+        });
+      }
+      for (auto& x : th) x.join();
+    }
+    *text = out_.p;
+    *text_len = off[good];
+    {
+      const auto t_d = std::chrono::steady_clock::now();
+      auto sec = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+      s_find += sec(t_a, t_b);
+      s_decode += sec(t_b, t_c);
+      s_stitch += sec(t_c, t_d);
+      pieces_started += n;
+      pieces_kept += good;
+    }
+    const Piece& last = piece(good - 1);
+    *next_bit = last.end_bit;
+    if (last.status == MkInflate::STREAM_END) return STREAM_END;
+    if (last.status == MkInflate::STOPPED) return MORE;
+    return (Result)last.status;  // (an error in the true stream: corrupt or truncated data)
+  }
+
+ private:
+  static constexpr uint64_t NONE = ~0ull;
+  struct Piece {
+    MkRawBuf<uint8_t> text8;    // piece 0: [WINDOW bytes of history][text]
+    MkRawBuf<uint16_t> text16;  // others:  [WINDOW place holders][elements]
+    size_t len = 0;
+    int status = MkInflate::BAD_DATA;
+    uint64_t end_bit = 0;
+  };
+
+  template <class T>
+  static void decode_loop(MkInflateT<T>& inf, MkRawBuf<T>& buf, Piece& p) {
+    size_t len = 0;
+    for (;;) {
+      size_t got = 0;
+      const auto st = inf.run(buf.p + WINDOW + len, buf.p + buf.cap, buf.p, &got);
+      len += got;
+      if (st != MkInflateT<T>::OUT_FULL) {
+        p.status = (int)st;
+        break;
+      }
+      if (!buf.reserve(buf.cap + buf.cap / 2 + 65536)) { p.status = MkInflate::BAD_DATA; break; }
+    }
+    p.len = len;
+    p.end_bit = inf.bit_position();
+  }
+  void decode_known(const uint8_t* base, const uint8_t* end, uint64_t from, uint64_t stop, const uint8_t* history,
+                    size_t history_len, Piece& p) const {
+    MkInflateT<uint8_t> inf;
+    inf.reset_at_bit(base, end, from);
+    inf.set_stop_bit(stop);
+    p.status = MkInflate::BAD_DATA;
+    p.len = 0;
+    if (!p.text8.reserve(WINDOW + piece_ * 5 + 65536)) return;
+    memset(p.text8.p, 0, WINDOW);
+    if (history_len > WINDOW) { history += history_len - WINDOW; history_len = WINDOW; }
+    if (history_len) memcpy(p.text8.p + WINDOW - history_len, history, history_len);
+    decode_loop(inf, p.text8, p);
+  }
+  void decode_unknown(const uint8_t* base, const uint8_t* end, uint64_t from, uint64_t stop, Piece& p) const {
+    MkInflateT<uint16_t> inf;
+    inf.reset_at_bit(base, end, from);
+    inf.set_stop_bit(stop);
+    p.status = MkInflate::BAD_DATA;
+    p.len = 0;
+    if (!p.text16.reserve(WINDOW + piece_ * 5 + 65536)) return;
+    for (size_t i = 0; i < WINDOW; ++i) p.text16.p[i] = (uint16_t)(256 + i);
+    decode_loop(inf, p.text16, p);
+  }
+
+  // First bit in [from, to) where a non-final dynamic block plausibly starts.
+  static uint64_t find_block(const uint8_t* base, const uint8_t* end, uint64_t from, uint64_t to) {
+    const uint64_t end_bit = (uint64_t)(end - base) * 8;
+    if (to > end_bit) to = end_bit;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    constexpr size_t TRIAL = 16384;
+    std::vector<uint16_t> scratch(WINDOW + TRIAL);
+    for (size_t i = 0; i < WINDOW; ++i) scratch[i] = (uint16_t)(256 + i);
+    MkInflateT<uint16_t> inf;
+    for (uint64_t b = from; b + 17 + 4 * 3 < to; ++b) {
+      // cheap filters on the raw bits: BFINAL = 0, BTYPE = 2, HLIT <= 29, HDIST <= 29, complete code-length code
+      const uint8_t* p = base + (b >> 3);
+      if (p + 12 > end) break;
+      uint64_t w;
+      memcpy(&w, p, 8);
+      w >>= (b & 7);  // >= 57 bits
+      if ((w & 7) != 4) continue;  // BFINAL 0, BTYPE 10b (read LSB first: bit0 = BFINAL, bits 1..2 = 2)
+      const unsigned hlit = (unsigned)(w >> 3) & 31, hdist = (unsigned)(w >> 8) & 31, hclen = ((unsigned)(w >> 13) & 15) + 4;
+      if (hlit > 29 || hdist > 29) continue;
+      {
+        // 17 header bits + up to 19 x 3 = 74 bits: take them from a second load
+        uint64_t w2;
+        memcpy(&w2, base + ((b + 17) >> 3), 8);
+        w2 >>= ((b + 17) & 7);  // >= 57 bits = 19 lengths
+        unsigned kraft = 0;
+        bool any = false;
+        for (unsigned i = 0; i < hclen; ++i) {
+          const unsigned l = (unsigned)(w2 >> (3 * i)) & 7;
+          if (l) { kraft += 128u >> l; any = true; }
+        }
+        (void)order;
+        if (!any || kraft != 128u) continue;
+      }
+      inf.reset_at_bit(base, end, b);
+      inf.set_strict(true);
+      size_t got = 0;
+      const auto st = inf.run(scratch.data() + WINDOW, scratch.data() + WINDOW + TRIAL, scratch.data(), &got);
+      if (st != MkInflateT<uint16_t>::OUT_FULL && st != MkInflateT<uint16_t>::STREAM_END) continue;
+      if (st == MkInflateT<uint16_t>::STREAM_END && got == 0) continue;
+      bool text = true;
+      for (size_t i = 0; i < got && text; ++i) {
+        const unsigned c = scratch[WINDOW + i];
+        text = c >= 256 || c == 9 || c == 10 || c == 13 || (c >= 32 && c < 127);
+      }
+      if (text) return b;
+    }
+    return NONE;
+  }
+
+  int threads_;
+  size_t piece_;
+  std::vector<std::unique_ptr<Piece>> piece_buf_;
+  MkRawBuf<uint8_t> out_;
+};
+
+// gzip framing around MkParallelInflate over a whole file in memory: header, rounds of parallel decoding,
+// CRC-32 / length trailer, further members, zero padding (as MkGzReader, which it matches output for output).
+class MkParallelGunzip {
+ public:
+  enum Status { MORE = 0, END = 1, BAD_DATA = -1, TRUNCATED = -2, BAD_HEADER = -3, BAD_CRC = -4 };
+  MkParallelGunzip(const uint8_t* data, size_t n, int threads, size_t piece_bytes)
+      : base_(data), end_(data + n), p_(data), par_(threads, piece_bytes) {}
+  int members() const { return members_; }
+  const MkParallelInflate& engine() const { return par_; }
+  // The next stretch of text (one round of pieces): *text / *len stay valid until the next call.
+  // END: nothing was produced, the file is done.
+  Status next(const uint8_t** text, size_t* len) {
+    *text = nullptr;
+    *len = 0;
+    if (!in_member_) {
+      while (p_ < end_ && *p_ == 0) ++p_;
+      if (p_ == end_) return END;
+      size_t hl = 0;
+      const int h = MkGzReader::header_length(p_, end_, &hl);
+      if (h) return h == 1 ? TRUNCATED : BAD_HEADER;
+      p_ += hl;
+      bit_ = (uint64_t)(p_ - base_) * 8;
+      in_member_ = true;
+      crc_ = mk_crc32(0, nullptr, 0);
+      len_ = 0;
+      hist_.clear();
+    }
+    uint64_t next_bit = 0;
+    const std::vector<uint8_t> hist(hist_);  // (the round may hand out the buffer the history points into)
+    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), text, len, &next_bit);
+    if (r < 0) return r == MkParallelInflate::TRUNCATED ? TRUNCATED : BAD_DATA;
+    const uint8_t* out = *text;
+    const size_t n = *len;
+    crc_ = mk_crc32(crc_, out, n);
+    len_ += n;
+    // the last 32 KiB of the member's text so far
+    if (n >= MkParallelInflate::WINDOW) {
+      hist_.assign(out + n - MkParallelInflate::WINDOW, out + n);
+    } else {
+      hist_.insert(hist_.end(), out, out + n);
+      if (hist_.size() > MkParallelInflate::WINDOW) hist_.erase(hist_.begin(), hist_.end() - MkParallelInflate::WINDOW);
+    }
+    bit_ = next_bit;
+    if (r == MkParallelInflate::STREAM_END) {
+      p_ = base_ + ((bit_ + 7) >> 3);
+      if (end_ - p_ < 8) return TRUNCATED;
+      const uint32_t crc = (uint32_t)p_[0] | ((uint32_t)p_[1] << 8) | ((uint32_t)p_[2] << 16) | ((uint32_t)p_[3] << 24);
+      const uint32_t isize = (uint32_t)p_[4] | ((uint32_t)p_[5] << 8) | ((uint32_t)p_[6] << 16) | ((uint32_t)p_[7] << 24);
+      if (crc != crc_ || isize != (uint32_t)len_) return BAD_CRC;
+      p_ += 8;
+      in_member_ = false;
+      ++members_;
+    }
+    return MORE;
+  }
+
+ private:
+  const uint8_t* base_;
+  const uint8_t* end_;
+  const uint8_t* p_;
+  MkParallelInflate par_;
+  bool in_member_ = false;
+  uint64_t bit_ = 0;
+  uint32_t crc_ = 0;
+  uint64_t len_ = 0;
+  int members_ = 0;
+  std::vector<uint8_t> hist_;
+};
+
+#endif

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "mk_write_tsv", "mk_export_pairs_device", "mk_import_pairs_device", "mk_export_exotic",
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
-    "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of",
+    "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of", "mk_gunzip_parallel",
 ]
 
 
@@ -121,6 +121,7 @@ def lib() -> C.CDLL:
         "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
         "mk_trim": (C.c_int, [vp]),
         "mk_alpha_stats": (C.c_int, [vp, C.POINTER(AlphaStats)]),
+        "mk_gunzip_parallel": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "mk_crc32_of": (C.c_uint32, [u8p, C.c_size_t, C.c_uint32]),
         "mk_gunzip": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "mk_stream_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
@@ -188,6 +189,18 @@ def gunzip(gz, cap: int, block: int = 4 << 20) -> Tuple[bytes, int]:
     rc = L.mk_gunzip(addr, n, out.ctypes.data, cap, int(block), C.byref(written), C.byref(members))
     if rc:
         raise MercatHipError(rc, "mk_gunzip")
+    return out[: written.value].tobytes(), members.value
+
+
+def gunzip_parallel(gz, cap: int, threads: int = 4, piece: int = 1 << 20) -> Tuple[bytes, int]:
+    """(text, members) through the parallel decoder (mk_gunzip_parallel)."""
+    L = lib()
+    addr, n, keep = _buf_ptr(gz)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    written, members = C.c_size_t(0), C.c_int(0)
+    rc = L.mk_gunzip_parallel(addr, n, out.ctypes.data, cap, int(threads), int(piece), C.byref(written), C.byref(members))
+    if rc:
+        raise MercatHipError(rc, "mk_gunzip_parallel")
     return out[: written.value].tobytes(), members.value
 
 

@@ -256,3 +256,24 @@ def test_count_file_bgzf_blocks_are_decoded_in_parallel(tmp_path):
         st = native.count_file([ctx], tmp_path / "mixed.fna.gz", 0, 2, threads=4)
         assert st["threads"] == 1 and st["members"] == nmembers + 1
         assert ctx.to_dict() == cpu_ref.count_text(text + b">tail\nACGTACGTACGTACGTACGTACGTAC\n", 21, 2)
+
+
+def test_count_file_plain_gzip_in_parallel(tmp_path, monkeypatch):
+    """An ordinary (single-stream) gzip file of more than 16 MiB is decoded by several threads at once
+    (block starts found by search); same table as front-to-back decoding and as the oracle."""
+    from oracle import c_oracle
+    data = native.synth_reads(300_000, 9, 400_000, 150, 10).tobytes()
+    path = tmp_path / "reads.fna.gz"
+    with gzip.GzipFile(path, "wb", compresslevel=1, mtime=0) as fh:
+        fh.write(data)
+    assert os.stat(path).st_size > (16 << 20)
+    want = c_oracle.count_dict(data, 25, 3)
+    tables = []
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("MK_GZ_SERIAL", "1")
+        with native.Counter(25, native.ALPHABET_NT2) as ctx:
+            st = native.count_file([ctx], path, 0, 3, threads=6)
+            assert st["threads"] == (1 if serial else 6) and st["members"] == 1 and st["text_bytes"] == len(data)
+            tables.append(ctx.to_dict())
+    assert tables[0] == tables[1] == want

@@ -122,3 +122,38 @@ def test_crc32_equals_zlib():
         piece = blob[a:a + n]
         addr, m, keep = native._buf_ptr(piece)
         assert L.mk_crc32_of(addr, m, seed) == zlib.crc32(piece, seed), (a, n, seed)
+
+
+@pytest.mark.parametrize("name", ["reads", "text", "runs", "far", "random", "short", "empty"])
+def test_parallel_decoder_equals_the_text(name):
+    """Several threads on one DEFLATE stream (mk_pgunzip.h): block starts found by search, unknown history
+    carried as place holders, pieces stitched together.  Small pieces put many seams into small files."""
+    data = TEXTS[name] * (6 if name in ("reads", "text") else 1)
+    for level, strategy in ((1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_FILTERED), (6, zlib.Z_FIXED), (0, 0)):
+        gz = _gz(data, level, strategy)
+        for threads, piece in ((1, 4096), (2, 4096), (4, 8192), (8, 4096), (3, 1 << 20)):
+            got, members = native.gunzip_parallel(gz, len(data), threads, piece)
+            assert got == data and members == 1, (name, level, strategy, threads, piece)
+
+
+def test_parallel_decoder_members_and_damage():
+    a, b = TEXTS["reads"] * 3, TEXTS["text"]
+    gz = _gz(a, 6, memlevel=2) + b"\0" * 5 + _gz(b, 1) + gzip.compress(b"")
+    got, members = native.gunzip_parallel(gz, len(a) + len(b), 4, 4096)
+    assert got == a + b and members == 3
+    one = _gz(a)
+    with pytest.raises(native.MercatHipError):
+        native.gunzip_parallel(one[:-5], len(a), 4, 4096)
+    bad = bytearray(one)
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(native.MercatHipError):
+        native.gunzip_parallel(bytes(bad), len(a) + 200_000, 4, 4096)
+    rng = random.Random(4)
+    for _ in range(60):       # damage anywhere: an error or (bits that do not matter) the text, never a crash
+        bad = bytearray(one)
+        for _ in range(rng.randint(1, 3)):
+            bad[rng.randrange(10, len(bad))] = rng.randrange(256)
+        try:
+            assert native.gunzip_parallel(bytes(bad), len(a) + 500_000, rng.choice([2, 5]), 4096)[0] == a
+        except native.MercatHipError:
+            pass

@@ -53,7 +53,7 @@ def main():
             w.write(_bgzf_member(b""))
         print("bgzf -> %.2f GB in %.1f s" % (os.path.getsize(bg) / 1e9, time.perf_counter() - t0))
     for f in [path] + ([gz] if gz else []) + ([bg] if bg else []):
-        for streams, threads in (((1, 0), (2, 0), (2, 2), (2, 16)) if not f.endswith('.gz') else (((2, 0), (2, 0), (2, 0)) if 'bgzf' not in f else ((2, 1), (2, 4), (2, 8), (2, 16)))):
+        for streams, threads in (((1, 0), (2, 0), (2, 2), (2, 16)) if not f.endswith('.gz') else (((2, 0), (2, 16), (2, 4), (2, 1)) if 'bgzf' not in f else ((2, 1), (2, 4), (2, 8), (2, 16)))):
             for rep in range(2):
                 out = os.path.join(d, "S2_counts_%d.tsv" % streams)
                 st = {}
