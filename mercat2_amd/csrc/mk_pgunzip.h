@@ -65,9 +65,10 @@ class MkParallelInflate {
   // compressed bytes.  The text is appended to out; *next_bit is where the next round starts (a block
   // header) or, at STREAM_END, the bit after the final block.
   Result round(const uint8_t* base, const uint8_t* end, uint64_t start_bit, const uint8_t* history, size_t history_len,
-               const uint8_t** text, size_t* text_len, uint64_t* next_bit) {
+               const uint8_t** text, size_t* text_len, uint64_t* next_bit, uint32_t* text_crc) {
     *text = nullptr;
     *text_len = 0;
+    *text_crc = mk_crc32(0, nullptr, 0);
     const uint64_t end_bit = (uint64_t)(end - base) * 8;
     const auto t_a = std::chrono::steady_clock::now();
     // ---- 1. piece starts: the verified one, then the first plausible block header after every cut
@@ -117,6 +118,7 @@ class MkParallelInflate {
     if (good == 1) {  // nothing to stitch: hand out the first piece's buffer as it is
       *text = piece(0).text8.p + WINDOW;
       *text_len = piece(0).len;
+      *text_crc = mk_crc32(0, *text, *text_len);
       *next_bit = piece(0).end_bit;
       return piece(0).status == MkInflate::STREAM_END ? STREAM_END : piece(0).status == MkInflate::STOPPED ? MORE : (Result)piece(0).status;
     }
@@ -141,17 +143,22 @@ class MkParallelInflate {
     {
       std::vector<std::thread> th;
       for (size_t t = 0; t < good; ++t) {
-        const Piece* pc = piece_buf_[t].get();
+        Piece* pc = piece_buf_[t].get();
         uint8_t* d = out_.p + off[t];
         const uint8_t* w = t ? win[t].data() : nullptr;
         th.emplace_back([=] {
           const size_t m = pc->len;
-          if (!w) { memcpy(d, pc->text8.p + WINDOW, m); return; }
-          const uint16_t* s = pc->text16.p + WINDOW;
-          for (size_t i = 0; i < m; ++i) d[i] = s[i] < 256 ? (uint8_t)s[i] : w[s[i] - 256];
+          if (!w) {
+            memcpy(d, pc->text8.p + WINDOW, m);
+          } else {
+            const uint16_t* s = pc->text16.p + WINDOW;
+            for (size_t i = 0; i < m; ++i) d[i] = s[i] < 256 ? (uint8_t)s[i] : w[s[i] - 256];
+          }
+          pc->crc = mk_crc32(0, d, m);  // (each piece's CRC here, in parallel; combined below)
         });
       }
       for (auto& x : th) x.join();
+      for (size_t t = 0; t < good; ++t) *text_crc = (uint32_t)crc32_combine(*text_crc, piece(t).crc, (z_off_t)piece(t).len);
     }
     *text = out_.p;
     *text_len = off[good];
@@ -179,6 +186,7 @@ class MkParallelInflate {
     size_t len = 0;
     int status = MkInflate::BAD_DATA;
     uint64_t end_bit = 0;
+    uint32_t crc = 0;
   };
 
   template <class T>
@@ -305,11 +313,12 @@ class MkParallelGunzip {
     }
     uint64_t next_bit = 0;
     const std::vector<uint8_t> hist(hist_);  // (the round may hand out the buffer the history points into)
-    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), text, len, &next_bit);
+    uint32_t round_crc = 0;
+    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), text, len, &next_bit, &round_crc);
     if (r < 0) return r == MkParallelInflate::TRUNCATED ? TRUNCATED : BAD_DATA;
     const uint8_t* out = *text;
     const size_t n = *len;
-    crc_ = mk_crc32(crc_, out, n);
+    crc_ = (uint32_t)crc32_combine(crc_, round_crc, (z_off_t)n);
     len_ += n;
     // the last 32 KiB of the member's text so far
     if (n >= MkParallelInflate::WINDOW) {
