@@ -2,7 +2,7 @@
 //
 // Same arithmetic as mk_part.hip (every window +1, keep count >= min_count;
 // lib/mercat2_kmers.py:56-60, 73-76) but the unit that travels through HBM is not the 8-byte
-// key of ONE window: it is a 16-byte record holding a run of up to 31 CONSECUTIVE windows that
+// key of ONE window: it is a 16-byte record holding a run of up to 8 CONSECUTIVE windows that
 // share their minimizer (a "super-k-mer": nk + k - 1 bases, 2 bits each, plus nk in 6 bits).
 //
 //   minimizer of a window = the 11-mer inside it with the smallest hash (leftmost on ties): a
@@ -12,13 +12,19 @@
 //   partition traffic drops from 8 B to ~2 B per window.
 //
 //   1 mk_sk_hist     per thread 32 windows: 11-mers, hashes, sliding minimum (doubling), runs;
-//                    records per bucket in an LDS histogram
-//   2 mk_part_scan   (mk_part.hip)
-//   3 mk_sk_scatter  same walk; rank of each record inside its (tile,bucket) run from an LDS
-//                    counter, one sweep of cursor atomics per tile, 16-byte record stores
-//   4 mk_sk_count    one workgroup per bucket: expand the records into k-mers and count them in
-//                    the LDS open-addressing table (same table, emit and sub-range splitting as
-//                    mk_part_count_k)
+//                    records and k-mers per bucket in LDS histograms.  Chunks of >= 8 Mbases look at one
+//                    thread in eight only (a sample)
+//   2 mk_sk_scan     bucket regions of the record buffer and of the survivor buffer in one pass; sampled
+//                    counts become capacities with room for the sampling error
+//   3 mk_sk_scatter  same walk over tiles of 2 x 1024 threads (the first sub-tile's analysis parked in
+//                    LDS); rank of each record inside its (tile,bucket) run from an LDS counter, one sweep
+//                    of cursor atomics per tile checked against the region ends, 16-byte record stores
+//   4 mk_sk_count    persistent, one workgroup per CU walks the buckets: expands the records into k-mers
+//                    and counts them in an LDS open-addressing table (claim-or-compare with one
+//                    compare-and-swap), emits entries with count >= min_count into the bucket's survivor
+//                    region, splits a bucket by further hash bits when its distinct keys do not fit
+//   A region that turns out too small (sampled sizes only) is never written past: the chunk is flagged
+//   (MkChunkInfo.part_overflow) and partitioned again from the exact histogram by the caller.
 #include "mk_common.h"
 #include "mk_device.h"
 #include <cstdlib>
@@ -31,9 +37,6 @@
 #define SK_NKMAX 8              // windows per record (<= 62 - k)
 #ifndef SK_HIST_THREADS
 #define SK_HIST_THREADS 256
-#endif
-#ifndef SK_ABL
-#define SK_ABL 0   // (timing experiments only)
 #endif
 #ifndef SK_HIST_GRID
 #define SK_HIST_GRID 512
@@ -755,7 +758,6 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 }
 
 // ------------------------------------------------------------------------------ launcher
-void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div);  // mk_part.hip
 
 template <int W>
 static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
@@ -832,8 +834,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   u64* cursor = start + p1 + 1;
   u64* khist = cursor + p1;
   u64* kstart = khist + p1;
-  u64* kcursor = kstart + p1 + 1;
-  u64* nsurv = kcursor + p1;
+  u64* nsurv = kstart + p1 + 1 + p1;  // (the p1 words in between: a cursor array the 8-byte-key path uses)
   MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   mk_prof_begin(c, MK_K_PART);
   switch (k - SK_M + 1) {
@@ -845,7 +846,6 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
       c->err = "mk_launch_count_superkmer: k out of range";
       return MK_ERR_ARG;
   }
-  (void)kcursor;
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {
