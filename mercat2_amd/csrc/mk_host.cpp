@@ -125,10 +125,11 @@ extern "C" int mk_gunzip_parallel(const uint8_t* gz, size_t n, uint8_t* out, siz
   if (!written || (n && !gz)) return MK_ERR_ARG;
   MkParallelGunzip rd(gz, n, threads, piece_bytes);
   size_t at = 0;
+  MkRawBuf<uint8_t> buf;
   for (;;) {
     const uint8_t* part = nullptr;
     size_t len = 0;
-    const MkParallelGunzip::Status s = rd.next(&part, &len);
+    const MkParallelGunzip::Status s = rd.next(buf, &part, &len);
     if (s == MkParallelGunzip::END) break;
     if (s != MkParallelGunzip::MORE) return s == MkParallelGunzip::TRUNCATED ? MK_ERR_RANGE : MK_ERR_IO;
     if (len > cap - at) return MK_ERR_NOMEM;

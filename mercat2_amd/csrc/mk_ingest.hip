@@ -176,13 +176,17 @@ static void gz_reader(Ring* R, const uint8_t* file, size_t file_len, const std::
 static void gz_parallel_reader(Ring* R, const uint8_t* file, size_t file_len, const std::string* path, int* members_out,
                                int threads) {
   MkParallelGunzip rd(file, file_len, threads, (size_t)4 << 20);
-  uint64_t i = 0;
+  MkRawBuf<uint8_t> buf[2];  // the text of one round is copied into the ring while the next round is decoded
+  std::thread copier;
+  std::atomic<bool> stop{false};
+  uint64_t i = 0;            // next ring block (touched by the copier only, one copier at a time)
   double s_copy = 0;
-  for (;;) {
+  for (unsigned r = 0;; ++r) {
     const uint8_t* text = nullptr;
     size_t n = 0;
-    const MkParallelGunzip::Status st = rd.next(&text, &n);
-    if (st == MkParallelGunzip::END) break;
+    const MkParallelGunzip::Status st = rd.next(buf[r & 1], &text, &n);
+    if (copier.joinable()) copier.join();  // (it read the other buffer, which the next round will overwrite)
+    if (st == MkParallelGunzip::END || stop.load()) break;
     if (st != MkParallelGunzip::MORE) {
       R->fail(MK_ERR_IO, *path + (st == MkParallelGunzip::TRUNCATED ? ": gzip stream is truncated"
                                   : st == MkParallelGunzip::BAD_HEADER ? ": not a gzip file (or data after the last member)"
@@ -190,20 +194,21 @@ static void gz_parallel_reader(Ring* R, const uint8_t* file, size_t file_len, co
                                                                      : ": corrupt gzip data"));
       break;
     }
-    bool stop = false;
-    const auto t0 = Clock::now();
-    for (size_t off = 0; off < n && !stop; off += R->block) {
-      const size_t m = n - off < R->block ? n - off : R->block;
-      if (!R->wait_writable(i)) { stop = true; break; }
-      memcpy(R->at(i), text + off, m);
-      R->publish(i, m, memchr(text + off, '\r', m) != nullptr);
-      ++i;
-    }
-    s_copy += seconds_since(t0);
-    if (stop) break;
+    copier = std::thread([R, text, n, &i, &stop, &s_copy] {
+      const auto t0 = Clock::now();
+      for (size_t off = 0; off < n; off += R->block) {
+        const size_t m = n - off < R->block ? n - off : R->block;
+        if (!R->wait_writable(i)) { stop.store(true); return; }
+        memcpy(R->at(i), text + off, m);
+        R->publish(i, m, memchr(text + off, '\r', m) != nullptr);
+        ++i;
+      }
+      s_copy += seconds_since(t0);
+    });
   }
+  if (copier.joinable()) copier.join();
   if (getenv("MK_VERBOSE"))
-    fprintf(stderr, "[mk] parallel gunzip: find %.3f s, decode %.3f s, stitch %.3f s, copy+wait %.3f s; pieces %zu started, %zu kept\n",
+    fprintf(stderr, "[mk] parallel gunzip: find %.3f s, decode %.3f s, stitch %.3f s, copy+wait %.3f s (overlapped); pieces %zu started, %zu kept\n",
             rd.engine().s_find, rd.engine().s_decode, rd.engine().s_stitch, s_copy, rd.engine().pieces_started, rd.engine().pieces_kept);
   *members_out = rd.members();
   R->set_total(i);

@@ -65,7 +65,7 @@ class MkParallelInflate {
   // compressed bytes.  The text is appended to out; *next_bit is where the next round starts (a block
   // header) or, at STREAM_END, the bit after the final block.
   Result round(const uint8_t* base, const uint8_t* end, uint64_t start_bit, const uint8_t* history, size_t history_len,
-               const uint8_t** text, size_t* text_len, uint64_t* next_bit, uint32_t* text_crc) {
+               MkRawBuf<uint8_t>& out_, const uint8_t** text, size_t* text_len, uint64_t* next_bit, uint32_t* text_crc) {
     *text = nullptr;
     *text_len = 0;
     *text_crc = mk_crc32(0, nullptr, 0);
@@ -115,13 +115,6 @@ class MkParallelInflate {
     // ---- 4. resolve the place holders: the window before each piece first (a chain), then the pieces at once
     std::vector<size_t> off(good + 1, 0);
     for (size_t t = 0; t < good; ++t) off[t + 1] = off[t] + piece(t).len;
-    if (good == 1) {  // nothing to stitch: hand out the first piece's buffer as it is
-      *text = piece(0).text8.p + WINDOW;
-      *text_len = piece(0).len;
-      *text_crc = mk_crc32(0, *text, *text_len);
-      *next_bit = piece(0).end_bit;
-      return piece(0).status == MkInflate::STREAM_END ? STREAM_END : piece(0).status == MkInflate::STOPPED ? MORE : (Result)piece(0).status;
-    }
     if (!out_.reserve(off[good] + 8)) return BAD_DATA;
     std::vector<std::vector<uint8_t>> win(good);  // win[t]: the WINDOW bytes before piece t (right-aligned)
     for (size_t t = 1; t < good; ++t) {
@@ -281,7 +274,6 @@ class MkParallelInflate {
   int threads_;
   size_t piece_;
   std::vector<std::unique_ptr<Piece>> piece_buf_;
-  MkRawBuf<uint8_t> out_;
 };
 
 // gzip framing around MkParallelInflate over a whole file in memory: header, rounds of parallel decoding,
@@ -293,9 +285,10 @@ class MkParallelGunzip {
       : base_(data), end_(data + n), p_(data), par_(threads, piece_bytes) {}
   int members() const { return members_; }
   const MkParallelInflate& engine() const { return par_; }
-  // The next stretch of text (one round of pieces): *text / *len stay valid until the next call.
-  // END: nothing was produced, the file is done.
-  Status next(const uint8_t** text, size_t* len) {
+  // The next stretch of text (one round of pieces) into `buf` (grown as needed); *text points into it.
+  // END: nothing was produced, the file is done.  The caller may hand a different buffer to every call
+  // (and so keep using the previous text while the next round runs).
+  Status next(MkRawBuf<uint8_t>& buf, const uint8_t** text, size_t* len) {
     *text = nullptr;
     *len = 0;
     if (!in_member_) {
@@ -314,7 +307,7 @@ class MkParallelGunzip {
     uint64_t next_bit = 0;
     const std::vector<uint8_t> hist(hist_);  // (the round may hand out the buffer the history points into)
     uint32_t round_crc = 0;
-    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), text, len, &next_bit, &round_crc);
+    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), buf, text, len, &next_bit, &round_crc);
     if (r < 0) return r == MkParallelInflate::TRUNCATED ? TRUNCATED : BAD_DATA;
     const uint8_t* out = *text;
     const size_t n = *len;
