@@ -95,13 +95,16 @@ def main(argv=None) -> int:
         # lines the reference prints per sample are kept and shown in sample order.
         tables = {}  # sample -> its table, kept on the GPU for the combined table
 
+        workers = max(1, min(int(args.n), 8, len(samples[kind])))
+        threads = max(2, 16 // workers)  # reader/decoder threads per sample: about 16 in all
+
         def one(item):
             base, f = item
             lines = []
             run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
-                       streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables)
+                       streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables,
+                       threads=threads if workers > 1 else 0)
             return lines
-        workers = max(1, min(int(args.n), 8, len(samples[kind])))
         if workers == 1:
             results = map(one, samples[kind].items())
         else:
