@@ -25,7 +25,9 @@
 #define SK2_SCAT_THREADS 1024
 #define SK2_MAX_P1 8192
 #define SK2_NKMAX 8
-#define SK2C_SLOTS 4096
+#ifndef SK2C_SLOTS
+#define SK2C_SLOTS 7168   // 20 bytes each: 140 KB of LDS; the most a 1024-thread sweep divides (4096: 25 % slower at k = 63, twice the sub-range passes)
+#endif
 #define SK2C_THREADS 1024
 #define SK2C_TARGET (SK2C_SLOTS * 6 / 10)
 #define SK2C_LOADCAP (SK2C_SLOTS * 3 / 4)
@@ -260,9 +262,12 @@ __device__ __forceinline__ unsigned sk2c_hash(u64 hi, u64 lo) {
   return h;
 }
 
+// Home slot of a hash (any table size).
+__device__ __forceinline__ unsigned sk2c_home(unsigned h) { return (unsigned)(((u64)h * SK2C_SLOTS) >> 32); }
+
 // Insert one 128-bit key (see the protocol in the header).
 __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
-  unsigned slot = h >> 20;  // SK2C_SLOTS == 4096
+  unsigned slot = sk2c_home(h);
   for (int probe = 0; probe < SK2C_MAX_PROBE;) {
     unsigned c = __hip_atomic_load(&tcnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (c == 0) {
@@ -281,7 +286,7 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
       atomicAdd(&tcnt[slot], 1u);
       return;
     }
-    slot = (slot + 1) & (SK2C_SLOTS - 1);
+    slot = slot + 1 == SK2C_SLOTS ? 0u : slot + 1;
     ++probe;
   }
   atomicOr(ovf, 1u);
@@ -350,11 +355,11 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           // the serial loop, which starts again at the home slot
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u)
-            st[u] = ((alive >> u) & 1u) ? __hip_atomic_load(&tcnt[hh[u] >> 20], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            st[u] = ((alive >> u) & 1u) ? __hip_atomic_load(&tcnt[sk2c_home(hh[u])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (((alive >> u) & 1u) && st[u] == 0) {
-              const unsigned slot = hh[u] >> 20;
+              const unsigned slot = sk2c_home(hh[u]);
               st[u] = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
               if (st[u] == 0) {
                 thi[slot] = khi[u];
@@ -370,13 +375,13 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             const bool look = ((alive >> u) & 1u) && !(st[u] & SK2C_LOCK);
-            oh[u] = look ? thi[hh[u] >> 20] : 0ull;
-            ol[u] = look ? tlo[hh[u] >> 20] : 0ull;
+            oh[u] = look ? thi[sk2c_home(hh[u])] : 0ull;
+            ol[u] = look ? tlo[sk2c_home(hh[u])] : 0ull;
           }
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (!((alive >> u) & 1u)) continue;
-            if (!(st[u] & SK2C_LOCK) && oh[u] == khi[u] && ol[u] == klo[u]) atomicAdd(&tcnt[hh[u] >> 20], 1u);
+            if (!(st[u] & SK2C_LOCK) && oh[u] == khi[u] && ol[u] == klo[u]) atomicAdd(&tcnt[sk2c_home(hh[u])], 1u);
             else sk2c_insert(thi, tlo, tcnt, ovf, khi[u], klo[u], hh[u]);
           }
           if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
