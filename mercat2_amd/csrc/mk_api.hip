@@ -353,7 +353,8 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_buf_reserve(c, c->ctab, c->ctab_slots * sizeof(MkSlot))) != MK_OK) return rc;
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
   }
-  const bool sk2 = c->mode == MK_MODE_HASH128 && c->use_superkmer2;  // partitioned path: no global chunk table
+  // partitioned path: no global chunk table (32-bit record indices in the scatter's LDS: chunks below 4 G symbols)
+  const bool sk2 = c->mode == MK_MODE_HASH128 && c->use_superkmer2 && seq_len < 0xFFFFFF00ull;
   if (c->mode == MK_MODE_BYREF || (c->mode == MK_MODE_HASH128 && !sk2)) {
     c->rtab_chunk_slots = pow2_at_least(2 * seq_len);
   } else if (bad_symbols) {

@@ -21,9 +21,12 @@
 #include <cstdlib>
 
 #define SK2_R 32
-#define SK2_HIST_THREADS 256
+#define SK2_HIST_THREADS 1024   // (two 64 KB LDS histograms per workgroup: one workgroup per CU)
 #define SK2_SCAT_THREADS 1024
-#define SK2_MAX_P1 8192
+#ifndef SK2_MAX_P1_LOG2
+#define SK2_MAX_P1_LOG2 13        // 8192 buckets (14 measured: the count kernel saves 1-2 ms per S2 step, the scatter
+#endif                           // loses 2: twice the cursor atomics and half the records per run)
+#define SK2_MAX_P1 (1 << SK2_MAX_P1_LOG2)
 #define SK2_NKMAX 8
 #ifndef SK2C_SLOTS
 #define SK2C_SLOTS 7168   // 20 bytes each: 140 KB of LDS; the most a 1024-thread sweep divides (4096: 25 % slower at k = 63, twice the sub-range passes)
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
                                                                      u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
                                                                      int p1_log2, int k, size_t ntiles) {
   __shared__ unsigned lh[SK2_MAX_P1];
-  __shared__ u64 gbase[SK2_MAX_P1];
+  __shared__ unsigned gbase[SK2_MAX_P1];  // (record indices stay below 2^32: the caller checks the chunk size)
   constexpr int NB = SK2_MAX_P1 / SK2_SCAT_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        if (b < p1) { gbase[b] = r[i]; lh[b] = 0; }
+        if (b < p1) { gbase[b] = (unsigned)r[i]; lh[b] = 0; }
       }
     }
     __syncthreads();
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
       const u64 w2 = codes[t + 2], w3 = codes[t + 3];
       sk2_walk(runs, w0, w1, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk2_bucket(mm, p1_log2);
-        part[gbase[b] + atomicAdd(&lh[b], 1u)] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
+        part[(size_t)gbase[b] + atomicAdd(&lh[b], 1u)] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
       });
     }
     __syncthreads();
@@ -458,8 +461,8 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int k = c->k;
   int p1_log2 = 8;
-  while (p1_log2 < 13 && (seq_len >> p1_log2) > 8192) ++p1_log2;
-  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= 13) p1_log2 = v; }
+  while (p1_log2 < SK2_MAX_P1_LOG2 && (seq_len >> p1_log2) > 8192) ++p1_log2;
+  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= SK2_MAX_P1_LOG2) p1_log2 = v; }
   c->p1_log2 = p1_log2;
   const size_t p1 = (size_t)1 << p1_log2;
   int rc;
@@ -481,7 +484,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   const size_t threads = div_up(seq_len, SK2_R), tiles = div_up(threads, SK2_HIST_THREADS);
   const size_t stiles = div_up(threads, SK2_SCAT_THREADS);
   mk_prof_begin(c, MK_K_PART);
-  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < 512 ? tiles : 512)), dim3(SK2_HIST_THREADS), 0, c->stream,
+  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(SK2_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads);
   mk_launch_part_scan(c, hist, start, cursor, p1_log2, 1);
   hipLaunchKernelGGL(mk_sk2_scatter_k, dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK2_SCAT_THREADS), 0,
