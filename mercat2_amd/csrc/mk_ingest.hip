@@ -406,6 +406,12 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   {
     const char* e = getenv("MK_INGEST_BLOCK");  // (tests shrink the blocks to put every boundary case in reach)
     R.block = e && atoll(e) > 0 ? (size_t)atoll(e) : ((size_t)4 << 20);
+    if (!(e && atoll(e) > 0)) {
+      // small samples: pinning the ring costs ~0.4 ms per MiB, more than reading the file -- size it to the text
+      const uint64_t text_guess = gz ? disk * 6 : disk;
+      while (R.block > ((size_t)64 << 10) && (uint64_t)R.block * 2 > text_guess + R.block / 2) R.block >>= 1;
+      if (auto_threads && text_guess <= ((uint64_t)8 << 20)) threads = 1;
+    }
   }
   void* gz_map = nullptr;
   bool gz_parallel = false;
