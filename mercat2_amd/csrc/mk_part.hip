@@ -251,6 +251,7 @@ __global__ __launch_bounds__(CNT_THREADS) void mk_part_count_k(const u64* __rest
     const double expect = (double)n / (dup_hint > 1.0 ? dup_hint : 1.0);
     while (s0 < SUB_BITS && expect / (double)(1u << s0) > (double)CNT_TARGET) ++s0;
     if (n <= CNT_LOADCAP) s0 = 0;
+    if (s0 > 3) s0 = 3;  // (see mk_skmer.hip: the estimate may be far too high for this bucket; overflows split further)
   }
   int s = s0;
   unsigned idx = 0;

@@ -73,6 +73,7 @@
 #define SKC_LOADCAP (SKC_SLOTS / 2)
 #define SKC_TARGET (SKC_SLOTS * SKC_TARGET_PCT / 100)
 #define SKC_SUB_BITS 16
+#define SKC_S0_MAX 3               // deepest sub-range split a bucket STARTS with (it splits on as tables overflow)
 
 static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
@@ -546,6 +547,10 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         const double expect = (double)n * nk_hint / (dup_hint > 1.0 ? dup_hint : 1.0);
         while (s0 < SKC_SUB_BITS && expect / (double)(1u << s0) > (double)SKC_TARGET) ++s0;
         if ((double)n * 31.0 <= (double)SKC_LOADCAP) s0 = 0;
+        // The estimate knows nothing about THIS bucket: a homopolymer puts millions of windows of one k-mer
+        // here, and 2^s0 passes over them took 30 s for 2 Mbases of poly-A.  Start no deeper than 8 sub-ranges;
+        // a sub-range that overflows is split further anyway, and its pass stops at the first overflow.
+        if (s0 > SKC_S0_MAX) s0 = SKC_S0_MAX;
         if (dflags & 16) s0 = 0;  // (timing experiments only)
       }
       int s = s0;

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
         const double expect = (double)n * nk_hint / (dup_hint > 1.0 ? dup_hint : 1.0);
         while (s0 < SK2C_SUB_BITS && expect / (double)(1u << s0) > (double)SK2C_TARGET) ++s0;
         if ((double)n * SK2_NKMAX <= (double)SK2C_LOADCAP) s0 = 0;
+        if (s0 > 3) s0 = 3;  // (see mk_skmer.hip: the estimate may be far too high for this bucket; overflows split further)
       }
       int s = s0;
       unsigned idx = 0;

@@ -589,3 +589,20 @@ def test_skewed_genome_like_input_at_scale_vs_c_oracle():
             st = ctx.stats()
         assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), (k, c)
         assert st["windows"] > 50_000_000
+
+
+def test_homopolymer_megabases_count_in_bounded_time():
+    """Millions of windows of ONE k-mer land in one bucket.  The count kernel used to start such a bucket at
+    the split depth its size suggested (2^16 passes over the records: 30 s for 2 Mbases of poly-A); it now
+    starts at most 8 sub-ranges deep and splits further only where a table overflows."""
+    import time
+    from oracle import c_oracle
+    data = b">a\n" + b"A" * 3_000_000 + b"\n>r\n" + b"ACGT" * 500_000 + b"\n>t\n" + b"T" * 200_000 + b"\n"
+    for k in (31, 32, 21, 40, 12):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            t0 = time.perf_counter()
+            ctx.count_chunk(data, 1)
+            got = ctx.to_dict()
+            dt = time.perf_counter() - t0
+        assert got == c_oracle.count_dict(data, k, 1), k
+        assert dt < 5.0, (k, dt)
