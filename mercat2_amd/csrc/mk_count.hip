@@ -194,19 +194,38 @@ __global__ __launch_bounds__(256) void mk_count_byref_k(const uint8_t* __restric
     long long since_sep = 0;  // consecutive non-separator bytes ending at the current byte
     long long since_bad = 1ll << 40;  // bytes since the last out-of-alphabet character (0 = current)
     const size_t last = (p0 + RB - 1 + k <= n) ? p0 + RB - 1 + k : n;  // exclusive end of bytes to read
+    // Runs of one character (the N gaps of an assembly: megabases) make every window the same k-mer, and
+    // adds to ONE slot are serialised by the L2: consecutive windows that lie inside such a run are
+    // counted together -- one insert with their number -- instead of one by one.
+    long long same = 0;       // consecutive equal bytes ending at the current byte
+    unsigned prev = 0x100;
+    u64 held_pos = 0, held_h = 0, held = 0;  // a run of identical windows not yet inserted
     for (size_t e = p0; e < last; ++e) {
       const unsigned ch = seq[e];
       h = h * MK_POLY_B + ch;
       if (e >= p0 + k) h -= bpow * (u64)seq[e - k];
       if (ch == MK_SEP) { since_sep = 0; } else { ++since_sep; }
       if (EXOTIC) { if (ch != MK_SEP && !in_alphabet(alphabet, ch)) since_bad = 0; else ++since_bad; }
+      same = ch == prev ? same + 1 : 1;
+      prev = ch;
       if (e + 1 >= p0 + k) {  // window [e-k+1, e] starts at >= p0
         if (since_sep >= k && (!EXOTIC || since_bad < k)) {
-          insert_ref(table, mask, seq, (u64)(e + 1 - k), mk_mix64(h), k, 1);
           ++mine;
+          if (same > k && held) {
+            ++held;  // the same k-mer as the window before (k + 1 equal bytes end here)
+          } else {
+            if (held) insert_ref(table, mask, seq, held_pos, held_h, k, held);
+            held = 0;
+            if (same >= k) { held = 1; held_pos = (u64)(e + 1 - k); held_h = mk_mix64(h); }
+            else insert_ref(table, mask, seq, (u64)(e + 1 - k), mk_mix64(h), k, 1);
+          }
+        } else if (held) {
+          insert_ref(table, mask, seq, held_pos, held_h, k, held);
+          held = 0;
         }
       }
     }
+    if (held) insert_ref(table, mask, seq, held_pos, held_h, k, held);
   }
   add_windows(info, mine, true);
 }

@@ -606,3 +606,33 @@ def test_homopolymer_megabases_count_in_bounded_time():
             dt = time.perf_counter() - t0
         assert got == c_oracle.count_dict(data, k, 1), k
         assert dt < 5.0, (k, dt)
+
+
+def test_input_shapes_vs_c_oracle():
+    """One megabase line, records of exactly k bases, an N gap, soft-masked (lower-case) stretches, wrapped and
+    CRLF-wrapped lines, blanks inside sequence lines: same tables as the C oracle, each within a second."""
+    import time
+    from oracle import c_oracle
+    rng = np.random.default_rng(1)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = 2_000_000
+    rand = acgt[rng.integers(0, 4, n)].tobytes()
+    shapes = {
+        "one_long_line": b">x\n" + rand + b"\n",
+        "tiny_records": b"".join(b">r%d\n" % i + rand[i * 31:i * 31 + 31] + b"\n" for i in range(n // 80)),
+        "n_gap": b">n\n" + rand[:1000] + b"N" * (n // 2) + rand[1000:2000] + b"\n",
+        "soft_masked": b">m\n" + b"".join((rand[i:i + 5000].lower() if (i // 5000) % 2 else rand[i:i + 5000]) for i in range(0, n // 2, 5000)) + b"\n",
+        "wrapped_60": b">w\n" + b"\n".join(rand[i:i + 60] for i in range(0, n, 60)) + b"\n",
+        "crlf_wrapped": b">w\r\n" + b"\r\n".join(rand[i:i + 70] for i in range(0, n // 2, 70)) + b"\r\n",
+        "blank_in_lines": b">b\n" + b"\n".join(rand[i:i + 30] + b" " + rand[i + 30:i + 60] for i in range(0, n // 4, 60)) + b"\n",
+    }
+    for name, data in shapes.items():
+        for k, c in ((21, 1), (31, 2), (40, 1)):
+            with native.Counter(k, native.ALPHABET_NT2) as ctx:
+                t0 = time.perf_counter()
+                ctx.count_chunk(data, c)
+                kmers, counts = ctx.export()
+                dt = time.perf_counter() - t0
+            okm, ocn = c_oracle.count(data, k, c)
+            assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), (name, k, c)
+            assert dt < 2.0, (name, k, dt)
