@@ -560,33 +560,38 @@ static int gather_ref(mk_ctx* c, ExportView& v, bool sorted) {
   if ((rc = mk_buf_reserve(c, c->ex_keys, rows * 8 + 64)) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->ex_cnts, rows * 8 + 64)) != MK_OK) return rc;
   u64* d_cursor = (u64*)((char*)c->info.p + sizeof(MkChunkInfo));
-  MK_HIP(hipMemsetAsync(d_cursor, 0, 8, c->stream));
+  MK_HIP(hipMemsetAsync(d_cursor, 0, 16, c->stream));  // [0] rows compacted, [1] rows with a bad index
   if ((rc = mk_launch_compact(c, (const MkSlot*)c->run_ref.p, c->run_ref_slots, (uint64_t*)c->ex_keys.p,
                               (uint64_t*)c->ex_cnts.p, rows, (uint64_t*)d_cursor)) != MK_OK) return rc;
-  std::vector<u64> keys(rows), cnts(rows);
+  // counts by arena row (the slots know their row), on the device
+  if ((rc = mk_buf_reserve(c, c->surv_cnts, rows * 8 + 64)) != MK_OK) return rc;
+  if ((rc = mk_launch_rows_by_slot(c, (const uint64_t*)c->ex_keys.p, (const uint64_t*)c->ex_cnts.p, rows,
+                                   (uint64_t*)c->surv_cnts.p, (uint64_t*)d_cursor + 1)) != MK_OK) return rc;
+  u64 got[2] = {0, 0};
   v.rstr.resize(rows * k);
-  MK_HIP(hipMemcpyAsync(keys.data(), c->ex_keys.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
-  MK_HIP(hipMemcpyAsync(cnts.data(), c->ex_cnts.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
-  MK_HIP(hipMemcpyAsync(v.rstr.data(), c->arena.p, rows * k, hipMemcpyDeviceToHost, c->stream));
-  u64 got = 0;
-  MK_HIP(hipMemcpyAsync(&got, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
-  MK_HIP(hipStreamSynchronize(c->stream));
-  if (got != rows) {
-    c->err = "export: by-reference table holds " + std::to_string(got) + " rows, expected " + std::to_string(rows);
-    return MK_ERR_STATE;
-  }
-  v.rcnt.assign(rows, 0);
-  for (size_t i = 0; i < rows; ++i) {
-    const u64 row = keys[i] & ((1ull << 40) - 1);
-    if (row >= rows) { c->err = "export: corrupt by-reference row index"; return MK_ERR_STATE; }
-    v.rcnt[row] = cnts[i];
-  }
+  v.rcnt.resize(rows);
   v.rorder.resize(rows);
   for (size_t i = 0; i < rows; ++i) v.rorder[i] = i;
   if (sorted) {
-    const uint8_t* base = v.rstr.data();
-    std::sort(v.rorder.begin(), v.rorder.end(),
-              [base, k](u64 a, u64 b) { return memcmp(base + a * k, base + b * k, k) < 0; });
+    // rows in byte order: radix sort of the row indices, then the rows and counts gathered in that order
+    // on the device, so that the host walks them front to back
+    uint64_t* d_order = nullptr;
+    if ((rc = mk_sort_rows(c, (const uint8_t*)c->arena.p, rows, c->k, &d_order)) != MK_OK) return rc;
+    if ((rc = mk_buf_reserve(c, c->surv_keys, rows * k + 64)) != MK_OK) return rc;
+    if ((rc = mk_launch_rows_gather(c, (const uint8_t*)c->arena.p, d_order, (const uint64_t*)c->surv_cnts.p, rows, c->k,
+                                    (uint8_t*)c->surv_keys.p, (uint64_t*)c->ex_keys.p)) != MK_OK) return rc;
+    MK_HIP(hipMemcpyAsync(v.rstr.data(), c->surv_keys.p, rows * k, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(v.rcnt.data(), c->ex_keys.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    MK_HIP(hipMemcpyAsync(v.rstr.data(), c->arena.p, rows * k, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipMemcpyAsync(v.rcnt.data(), c->surv_cnts.p, rows * 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  MK_HIP(hipMemcpyAsync(got, d_cursor, 16, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  if (got[0] != rows || got[1] != 0) {
+    c->err = "export: by-reference table holds " + std::to_string(got[0]) + " rows (" + std::to_string(got[1]) +
+             " with a corrupt row index), expected " + std::to_string(rows);
+    return MK_ERR_STATE;
   }
   return MK_OK;
 }

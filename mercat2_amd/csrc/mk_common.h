@@ -190,6 +190,11 @@ int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_
 // tables
 int mk_launch_clear_slots(mk_ctx* c, MkSlot* t, size_t slots);
 int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count);
+// mk_sort.hip: arena rows (k bytes each) in byte order; *d_order = row indices, sorted (lives in c->ex_cnts2)
+int mk_sort_rows(mk_ctx* c, const uint8_t* d_arena, size_t rows, int k, uint64_t** d_order);
+int mk_launch_rows_by_slot(mk_ctx* c, const uint64_t* slot_keys, const uint64_t* slot_cnts, size_t rows, uint64_t* cnt_by_row, uint64_t* d_bad);
+int mk_launch_rows_gather(mk_ctx* c, const uint8_t* arena, const uint64_t* order, const uint64_t* cnt_by_row, size_t rows, int k,
+                          uint8_t* out_rows, uint64_t* out_cnts);
 int mk_launch_alpha(mk_ctx* c, unsigned long long* d_out);  // 16 words: see mk_alpha_k
 int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
