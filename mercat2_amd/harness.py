@@ -92,10 +92,10 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
     survivors on the GPU, write the TSV sorted by k-mer.  ``num_cores`` is accepted and unused,
     as in the reference."""
     files = list(files)
-    first = read_fasta_bytes(files[0]) if files else b""
-    with native.Counter(kmer, guess_alphabet(files[0] if files else "", first), device) as ctx:
-        for i, f in enumerate(files):
-            ctx.count_chunk(first if i == 0 else read_fasta_bytes(f), min_count)
+    alphabet = guess_alphabet(files[0], read_head(files[0])) if files else native.ALPHABET_NT2
+    with native.Counter(kmer, alphabet, device) as ctx:
+        for f in files:
+            native.count_file([ctx], f, 0, min_count)  # every file is one find_kmers call: filtered on its own
         return _finish(ctx, basename, out_file)
 
 
