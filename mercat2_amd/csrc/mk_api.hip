@@ -390,12 +390,25 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if (!c->part_sampled) { c->err = "partition overflow without sampling (internal error)"; return MK_ERR_STATE; }
     MkChunkInfo* h = c->h_info;
     if (getenv("MK_VERBOSE")) fprintf(stderr, "[mk] sampled partition too small (where=%llu: 1 records total, 2 survivors total, 4 a bucket, 8 a survivor region): exact pass\n", h->part_overflow);
+    // (the fields the partitioned kernels own; what the by-reference kernel added for odd windows stays)
     h->windows = h->records = h->distinct = h->survivors = h->side = h->errors = h->part_overflow = 0;
     MK_HIP(hipMemcpyAsync(c->info.p, h, sizeof(MkChunkInfo), hipMemcpyHostToDevice, c->stream));
     c->st.part_retries += 1;
-    if ((rc = mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true)) != MK_OK) return rc;
+    rc = sk2 ? mk_launch_count_superkmer2(c, seq_len, min_count, /*exact=*/true)
+             : mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true);
+    if (rc) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
   }
+  // the two-word kernels report in the one-word path's fields (they may have to be discarded on their own):
+  // fold them into the by-reference totals of the host copy after every read-back
+  auto fold_sk2 = [&]() {
+    if (!sk2) return;
+    c->h_info->exotic += c->h_info->windows;
+    c->h_info->survivors_ref += c->h_info->survivors;
+    c->h_info->windows = 0;
+    c->h_info->survivors = 0;
+  };
+  fold_sk2();
   if (c->h_info->errors) {
     c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";
     return MK_ERR_RANGE;
@@ -428,6 +441,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   }
   if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
+  fold_sk2();
   c->run_rows += (size_t)c->h_info->new_rows;
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;

@@ -183,8 +183,12 @@ int mk_launch_count_ref128(mk_ctx* c, size_t seq_len);
 int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip
 int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
+// mk_skmer.hip: bucket regions (records and survivors) from an exact or sampled histogram, in one kernel
+void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned long long* khist, unsigned long long* start,
+                       unsigned long long* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
+                       unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
-int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count);
+int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,
                                     const uint64_t* kstart, const uint64_t* nsurv, size_t p1);
 // tables

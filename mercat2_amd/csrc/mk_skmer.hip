@@ -764,6 +764,12 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 
 // ------------------------------------------------------------------------------ launcher
 
+void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start, u64* cursor, u64* kstart, int p1_log2,
+                       int sample_log2, int nkmax, u64 surv_div, u64 part_cap, u64 surv_cap, float sigmas) {
+  hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, khist, start, cursor, kstart,
+                     (MkChunkInfo*)c->info.p, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
+}
+
 template <int W>
 static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
                      u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart) {

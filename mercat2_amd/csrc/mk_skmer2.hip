@@ -161,28 +161,29 @@ __device__ __forceinline__ Sk2Rec sk2_make_record(u64 w0, u64 w1, u64 w2, u64 w3
 }
 
 // ------------------------------------------------------------------------------ hist / scatter
+// (sample_log2 > 0: one pseudo-randomly chosen analysis thread of every 2^sample_log2, as in mk_skmer.hip)
 __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
-                                                                  MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
+                                                                  const MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                   u64* __restrict__ khist, int p1_log2, int k,
-                                                                  size_t nthreads_total) {
+                                                                  size_t nthreads_total, int sample_log2) {
   __shared__ unsigned lh[SK2_MAX_P1];
   __shared__ unsigned lk[SK2_MAX_P1];
   const unsigned p1 = 1u << p1_log2;
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) { lh[i] = 0; lk[i] = 0; }
   __syncthreads();
   const size_t seq_len = info->seq_len;
-  u64 mine = 0, recs = 0;
-  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < nthreads_total; t += (size_t)gridDim.x * blockDim.x) {
+  const size_t ngroups = (nthreads_total + ((size_t)1 << sample_log2) - 1) >> sample_log2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (size_t)gridDim.x * blockDim.x) {
+    size_t t = g;
+    if (sample_log2) t = (g << sample_log2) + (((unsigned)g * 0x9E3779B1u >> 7) & ((1u << sample_log2) - 1));
     const size_t p0 = t * SK2_R;
-    if (p0 >= seq_len) break;
+    if (t >= nthreads_total || p0 >= seq_len) continue;
     const u64 w0 = codes[t], w1 = codes[t + 1];
     const Sk2Runs r = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
     sk2_walk(r, w0, w1, [&](int, int nk, unsigned mm) {
       const unsigned b = sk2_bucket(mm, p1_log2);
       atomicAdd(&lh[b], 1u);
       atomicAdd(&lk[b], (unsigned)nk);
-      mine += (u64)nk;
-      ++recs;
     });
   }
   __syncthreads();
@@ -193,16 +194,19 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
       atomicAdd(&khist[b], (u64)lk[b]);
     }
   }
-  block_add(&info->exotic, mine);  // these windows are counted outside the packed-key table: "by reference" totals
-  block_add(&info->records, recs);
 }
 
 __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
-                                                                     const MkChunkInfo* __restrict__ info,
+                                                                     MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                      u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
                                                                      int p1_log2, int k, size_t ntiles) {
   __shared__ unsigned lh[SK2_MAX_P1];
   __shared__ unsigned gbase[SK2_MAX_P1];  // (record indices stay below 2^32: the caller checks the chunk size)
+  __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
+  if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
+  __syncthreads();
+  if (s_abort) return;  // the regions do not fit the buffers: nothing may be written
+  unsigned spilled = 0;
   constexpr int NB = SK2_MAX_P1 / SK2_SCAT_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
@@ -238,7 +242,13 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        if (b < p1) { gbase[b] = (unsigned)r[i]; lh[b] = 0; }
+        if (b < p1) {
+          // a run that would cross the end of its bucket's region (sampled sizes only) is not written
+          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+          spilled |= fits ? 0u : 1u;
+          gbase[b] = fits ? (unsigned)r[i] : ~0u;
+          lh[b] = 0;
+        }
       }
     }
     __syncthreads();
@@ -246,13 +256,16 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
       const u64 w2 = codes[t + 2], w3 = codes[t + 3];
       sk2_walk(runs, w0, w1, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk2_bucket(mm, p1_log2);
-        part[(size_t)gbase[b] + atomicAdd(&lh[b], 1u)] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
+        const unsigned base = gbase[b];
+        const unsigned rank = atomicAdd(&lh[b], 1u);
+        if (base != ~0u) part[(size_t)base + rank] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
       });
     }
     __syncthreads();
     for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
     __syncthreads();
   }
+  if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
 
 // ------------------------------------------------------------------------------------- count
@@ -296,6 +309,7 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
 }
 
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
+                                                               const u64* __restrict__ cursor,
                                                                const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                                MkChunkInfo* __restrict__ info, u64 min_count,
                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
@@ -305,19 +319,27 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
   __shared__ u64 tlo[SK2C_SLOTS];
   __shared__ unsigned tcnt[SK2C_SLOTS];
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
+  __shared__ unsigned long long s_windows;
+  __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
+  if (threadIdx.x == 0) { s_abort = info->part_overflow != 0; s_windows = 0; }
+  __syncthreads();
+  if (s_abort) return;  // the scatter did not fit its (sampled) regions: the chunk is partitioned again
   for (unsigned i = threadIdx.x; i < SK2C_SLOTS; i += blockDim.x) tcnt[i] = 0;
   if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
   __syncthreads();
   unsigned par = 0;
   const int lane = threadIdx.x & 63;
   const u64 lomask = (k >= 64) ? ~0ull : (~0ull << (128 - 2 * k));
-  u64 distinct_total = 0, survivors_total = 0, nerr = 0;
+  u64 distinct_total = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
-    const u64 lo_r = start[b], n = start[b + 1] - lo_r;
+    const u64 lo_r = start[b], n = cursor[b] - lo_r;  // (the scatter's cursor ends where the bucket's records end)
     u64* __restrict__ my_hi = out_hi + kstart[b];
     u64* __restrict__ my_lo = out_lo + kstart[b];
     u64* __restrict__ my_cnt = out_cnt + kstart[b];
+    const u64 region = kstart[b + 1] - kstart[b];
     unsigned emitted = 0;
+    bool counted = false;  // the bucket's windows have been added to the chunk's total
+    records_total += n;
     if (n >> 27) {
       ++nerr;
     } else if (n) {
@@ -334,9 +356,11 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
       for (;;) {
         const unsigned sel_shift = SK2C_SUB_BITS - s;
         unsigned* const ovf = &s_overflow[par];
+        u64 win_pass = 0;
         for (u64 j = threadIdx.x; j < n; j += SK2C_THREADS) {
           const Sk2Rec rec = src[j];
           const int nk = (int)rec.nk;  // <= SK2_NKMAX
+          win_pass += counted ? 0 : (u64)nk;
           u64 khi[SK2_NKMAX], klo[SK2_NKMAX];
           unsigned hh[SK2_NKMAX], st[SK2_NKMAX];
           unsigned alive = 0;
@@ -414,9 +438,13 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           if (mine) {
             const unsigned at = emitted + atomicAdd(&s_emit[par], mine);
             unsigned o = 0;
+            if ((u64)at + mine > region) {  // only a region sized from a sampled histogram can be too small
+              atomicOr(&info->part_overflow, 8ull);
+              mine = 0;
+            }
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-              if (ec[q]) {
+              if (mine && ec[q]) {
                 my_hi[at + o] = eh[q];
                 my_lo[at + o] = el[q];
                 my_cnt[at + o] = ec[q];
@@ -434,6 +462,8 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           s += 1;
           idx <<= 1;
         } else {
+          windows += win_pass;  // (a pass that ran to its end has seen every record once)
+          counted = true;
           while (s > s0 && (idx & 1u)) { idx >>= 1; --s; }
           if (s == s0) {
             ++idx;
@@ -447,17 +477,24 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
     if (threadIdx.x == 0) nsurv[b] = emitted;
     survivors_total += emitted;
   }
+  {  // one global add per workgroup
+    for (int d = 32; d > 0; d >>= 1) windows += __shfl_down(windows, d);
+    if (lane == 0 && windows) atomicAdd(&s_windows, (unsigned long long)windows);
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
+    // windows / survivors of THIS kernel go to the fields the one-word path uses; the caller folds them into
+    // the by-reference totals once the chunk is known to be complete (they may have to be discarded)
+    if (s_windows) atomicAdd(&info->windows, (u64)s_windows);
+    if (records_total) atomicAdd(&info->records, records_total);
     if (distinct_total) atomicAdd(&info->distinct, distinct_total);
-    if (survivors_total) atomicAdd(&info->survivors_ref, survivors_total);
+    if (survivors_total) atomicAdd(&info->survivors, survivors_total);
     if (nerr) atomicAdd(&info->errors, nerr);
   }
 }
 
 // ------------------------------------------------------------------------------------ launcher
-void mk_launch_part_scan(mk_ctx* c, const u64* hist, u64* start, u64* cursor, int p1_log2, u64 div);  // mk_part.hip
-
-int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
+int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact) {
   if (seq_len == 0) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int k = c->k;
@@ -466,11 +503,28 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= SK2_MAX_P1_LOG2) p1_log2 = v; }
   c->p1_log2 = p1_log2;
   const size_t p1 = (size_t)1 << p1_log2;
+  // bucket sizes from a 1-in-8 sample of the analysis threads for big chunks (see mk_skmer.hip)
+  int sample_log2 = 0;
+  float sigmas = 6.0f;
+  {
+    int want = 3;
+    size_t min_len = (size_t)8 << 20;
+    if (const char* e = getenv("MK_SAMPLE_LOG2")) { int v = atoi(e); if (v >= 0 && v <= 6) want = v; }
+    if (const char* e = getenv("MK_SAMPLE_MIN")) min_len = (size_t)atoll(e);
+    if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = (float)atof(e);
+    if (!exact && seq_len >= min_len) sample_log2 = want;
+  }
+  c->part_sampled = sample_log2 != 0;
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
-  if ((rc = mk_buf_reserve(c, c->part, (seq_len + 64) * sizeof(Sk2Rec))) != MK_OK) return rc;
+  const size_t part_cap = seq_len + 64;
+  if ((rc = mk_buf_reserve(c, c->part, part_cap * sizeof(Sk2Rec))) != MK_OK) return rc;
   const u64 surv_div = min_count > 1 ? (u64)min_count : 1;  // <= ceil(m / min_count) survivors among m k-mers
-  const size_t surv_cap = seq_len / surv_div + p1 + 64;
+  size_t surv_cap = seq_len / surv_div + p1 + 64;
+  if (sample_log2) {  // room for the sampling error of every bucket (bound as in mk_skmer.hip)
+    const double L = 1.25 * (double)seq_len, S = (double)(1u << sample_log2), w = (double)SK2_R;
+    surv_cap = (size_t)((L + 6.0 * sqrt((double)p1 * S * w * L) + 16.0 * w * (double)p1) / (double)surv_div) + 2 * p1 + 64;
+  }
   if ((rc = mk_buf_reserve(c, c->surv_keys, surv_cap * sizeof(u64))) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->surv_keys2, surv_cap * sizeof(u64))) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
@@ -482,16 +536,19 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   u64* kcursor = kstart + p1 + 1;
   u64* nsurv = kcursor + p1;
   MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
-  const size_t threads = div_up(seq_len, SK2_R), tiles = div_up(threads, SK2_HIST_THREADS);
+  const size_t threads = div_up(seq_len, SK2_R);
+  const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK2_HIST_THREADS);
   const size_t stiles = div_up(threads, SK2_SCAT_THREADS);
+  const size_t hist_grid = sample_log2 ? 128 : 256;
+  (void)kcursor;
   mk_prof_begin(c, MK_K_PART);
-  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(SK2_HIST_THREADS), 0, c->stream,
-                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads);
-  mk_launch_part_scan(c, hist, start, cursor, p1_log2, 1);
+  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK2_HIST_THREADS), 0, c->stream,
+                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
+  mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
+                    (u64)surv_cap, sigmas);
   hipLaunchKernelGGL(mk_sk2_scatter_k, dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK2_SCAT_THREADS), 0,
-                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, cursor, (Sk2Rec*)c->part.p, p1_log2, k,
-                     stiles);
-  mk_launch_part_scan(c, khist, kstart, kcursor, p1_log2, surv_div);
+                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
+                     (Sk2Rec*)c->part.p, p1_log2, k, stiles);
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {
@@ -499,7 +556,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count) {
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
     hipLaunchKernelGGL(mk_sk2_count_k, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
-                       (const u64*)start, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                       (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                        (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
   }
   mk_prof_end(c);

@@ -548,7 +548,7 @@ def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_
     data = native.synth_reads(200_000, 41, 60_000, 150, 42).tobytes()
     low = b">poly\n" + b"A" * 30_000 + b"\n>rep\n" + b"ACGTTGCAAG" * 4_000 + b"\n"
     from oracle import c_oracle
-    for k, c in ((21, 2), (31, 1), (32, 3)):
+    for k, c in ((21, 2), (31, 1), (32, 3), (40, 2), (63, 1)):      # one-word and two-word keys
         for payload in (data, data + low):
             half = payload[: len(payload) // 2]
             want = cpu_ref.merge_counts([c_oracle.count_dict(payload, k, c), c_oracle.count_dict(half, k, c)])
