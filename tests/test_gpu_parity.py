@@ -581,7 +581,7 @@ def test_skewed_genome_like_input_at_scale_vs_c_oracle():
              b"\n>ac\n", b"AC" * 1_000_000, b"\n>gaps\n", genome[12_000_000:16_000_000], b"N" * 5000,
              genome[16_000_000:], b"\n", reads, b">chr1_again\n", genome[:6_000_000], b"\n"]
     data = b"".join(parts)
-    for k, c in ((31, 2), (21, 3)):
+    for k, c in ((31, 2), (21, 3), (45, 2)):
         okm, ocn = c_oracle.count(data, k, c)
         with native.Counter(k, native.ALPHABET_NT2) as ctx:
             ctx.count_chunk(data, c)
