@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--read-seed", type=int, default=READ_SEED)
     ap.add_argument("--sub-ppm", type=int, default=0, help="per-base substitution rate, parts per million (S2e: 10000)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--canonical", action="store_true",
+                    help="count min(kmer, reverse complement) (BASELINE config 3 names it; an opt-in extension, not the "
+                         "reference's forward-strand behaviour -- the default run keeps that)")
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "0")),
                     help="engine contexts (HIP streams) per GPU; chunks are dealt round-robin and counted "
                          "concurrently, the tables are merged on the device at the end of the step")
@@ -124,7 +127,7 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
     nctx = args.contexts if args.contexts > 0 else native.default_streams(args.k, native.ALPHABET_NT2)
-    ctxs = [native.Counter(k, native.ALPHABET_NT2, device=local) for _ in range(nctx)]
+    ctxs = [native.Counter(k, native.ALPHABET_NT2, device=local, canonical=args.canonical and k <= 32) for _ in range(nctx)]
     ctx = ctxs[0]
     pool = ThreadPoolExecutor(nctx) if nctx > 1 else None
     key_bits = 2 * k
@@ -229,8 +232,9 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "%s: %d reads x %d bp per GPU from a %d bp genome, k=%d, -c %d, -s %d (%d chunks), "
-                                   "forward-strand keys" % ("S2" if (args.reads, args.genome, k, args.sub_ppm) == (READS, GENOME, K, 0) else "custom",
-                                                            args.reads, READ_LEN, args.genome, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1),
+                                   "%s keys" % ("S2" if (args.reads, args.genome, k, args.sub_ppm) == (READS, GENOME, K, 0) else "custom",
+                                                            args.reads, READ_LEN, args.genome, k, MIN_COUNT, CHUNK_MIB, len(offs) - 1,
+                                                            "canonical" if (args.canonical and k <= 32) else "forward-strand"),
                        "reads_per_gpu": args.reads, "read_len": READ_LEN, "k": k, "min_count": MIN_COUNT,
                        "chunk_mib": CHUNK_MIB, "chunks": len(offs) - 1, "mode": st["mode_name"], "contexts_per_gpu": nctx,
                        "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
