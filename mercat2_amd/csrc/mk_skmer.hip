@@ -211,7 +211,7 @@ __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart,
 // is looked at: the scan below turns the sampled counts into capacities with room for the sampling
 // error, the scatter checks every reservation against them, and a chunk whose estimate was too
 // small anywhere is partitioned again with s = 0 (exact).
-template <int W>
+template <int W, bool CANON>
 __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                 const MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                 u64* __restrict__ khist, int p1_log2, int k, int nkmax,
@@ -230,7 +230,8 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
     if (t >= nthreads_total || p0 >= seq_len) continue;
     const u64 w0 = codes[t], w1 = codes[t + 1];
     const u64 badw = bad_window(bad, p0);
-    sk_for_each_record<W>(w0, w1, badw, k, nkmax, canon != 0, [&](int, int nk, unsigned mm) {
+    (void)canon;
+    sk_for_each_record<W>(w0, w1, badw, k, nkmax, CANON, [&](int, int nk, unsigned mm) {
       const unsigned b = sk_bucket(mm, p1_log2);
       atomicAdd(&lh[b], 1u);
       atomicAdd(&lk[b], (unsigned)nk);
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ his
 }
 
 // --------------------------------------------------------------------------- 3 scatter
-template <int W>
+template <int W, bool CANON>
 __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                    MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                    u64* __restrict__ cursor, ulonglong2* __restrict__ part,
@@ -352,8 +353,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
       if (p0 < seq_len) {
         ww0 = codes[t];
         ww1 = codes[t + 1];
-        runs = sk_analyse<W>(ww0, ww1, sk_valid32(bad_window(bad, p0), k), canon != 0);
-        sk_walk(runs, ww0, ww1, nkmax, canon != 0,
+        runs = sk_analyse<W>(ww0, ww1, sk_valid32(bad_window(bad, p0), k), CANON);
+        sk_walk(runs, ww0, ww1, nkmax, CANON,
                 [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
       }
       if (st + 1 < SK_SCAT_SUBT) {
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
         ww1 = w.y;
       }
       const u64 w0 = ww0, w1 = ww1;
-      sk_walk(runs, w0, w1, nkmax, canon != 0, [&](int jstart, int nk, unsigned mm) {
+      (void)canon;
+      sk_walk(runs, w0, w1, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
         const unsigned base = gbase[b];
         const unsigned rank = atomicAdd(&lh[b], 1u);
@@ -770,8 +772,8 @@ void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start,
                      (MkChunkInfo*)c->info.p, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
 }
 
-template <int W>
-static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
+template <int W, bool CANON>
+static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
                      u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   float sigmas = 6.0f;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
@@ -781,12 +783,12 @@ static void launch_w(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int samp
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
   const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
-  hipLaunchKernelGGL((mk_sk_hist_k<W>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
+  hipLaunchKernelGGL((mk_sk_hist_k<W, CANON>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
                      (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
                      sample_log2);
   hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
                      info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
-  hipLaunchKernelGGL((mk_sk_scatter_k<W>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
+  hipLaunchKernelGGL((mk_sk_scatter_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
                      (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
 }
@@ -849,7 +851,11 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   mk_prof_begin(c, MK_K_PART);
   switch (k - SK_M + 1) {
-#define SK_CASE(W) case W: launch_w<W>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); break;
+#define SK_CASE(W)                                                                                                      \
+  case W:                                                                                                               \
+    if (c->canonical) launch_wc<W, true>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); \
+    else launch_wc<W, false>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); \
+    break;
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
     SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
 #undef SK_CASE
