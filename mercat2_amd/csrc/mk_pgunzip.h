@@ -183,7 +183,7 @@ class MkParallelInflate {
   };
 
   template <class T>
-  static void decode_loop(MkInflateT<T>& inf, MkRawBuf<T>& buf, Piece& p) {
+  static void decode_loop(MkInflateT<T>& inf, MkRawBuf<T>& buf, Piece& p, size_t limit) {
     size_t len = 0;
     for (;;) {
       size_t got = 0;
@@ -193,7 +193,9 @@ class MkParallelInflate {
         p.status = (int)st;
         break;
       }
-      if (!buf.reserve(buf.cap + buf.cap / 2 + 65536)) { p.status = MkInflate::BAD_DATA; break; }
+      // (a piece that inflates more than 256-fold is not text worth decoding 16 at a time: refuse rather than
+      // let a crafted file take the host's memory; MK_GZ_SERIAL=1 streams such a file through fixed blocks)
+      if (buf.cap > limit || !buf.reserve(buf.cap + buf.cap / 2 + 65536)) { p.status = MkInflate::BAD_DATA; break; }
     }
     p.len = len;
     p.end_bit = inf.bit_position();
@@ -209,7 +211,7 @@ class MkParallelInflate {
     memset(p.text8.p, 0, WINDOW);
     if (history_len > WINDOW) { history += history_len - WINDOW; history_len = WINDOW; }
     if (history_len) memcpy(p.text8.p + WINDOW - history_len, history, history_len);
-    decode_loop(inf, p.text8, p);
+    decode_loop(inf, p.text8, p, (piece_ * 256 > ((size_t)64 << 20) ? piece_ * 256 : ((size_t)64 << 20)) + WINDOW);
   }
   void decode_unknown(const uint8_t* base, const uint8_t* end, uint64_t from, uint64_t stop, Piece& p) const {
     MkInflateT<uint16_t> inf;
@@ -219,7 +221,7 @@ class MkParallelInflate {
     p.len = 0;
     if (!p.text16.reserve(WINDOW + piece_ * 5 + 65536)) return;
     for (size_t i = 0; i < WINDOW; ++i) p.text16.p[i] = (uint16_t)(256 + i);
-    decode_loop(inf, p.text16, p);
+    decode_loop(inf, p.text16, p, (piece_ * 256 > ((size_t)64 << 20) ? piece_ * 256 : ((size_t)64 << 20)) + WINDOW);
   }
 
   // First bit in [from, to) where a non-final dynamic block plausibly starts.
