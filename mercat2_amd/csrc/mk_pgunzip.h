@@ -58,7 +58,9 @@ class MkParallelInflate {
   double s_find = 0, s_decode = 0, s_stitch = 0;  // seconds per phase, summed over the rounds
   size_t pieces_started = 0, pieces_kept = 0;
 
-  MkParallelInflate(int threads, size_t piece_bytes) : threads_(threads < 1 ? 1 : threads), piece_(piece_bytes < 4096 ? 4096 : piece_bytes) {}
+  MkParallelInflate(int threads, size_t piece_bytes) : threads_(threads < 1 ? 1 : threads), piece_(piece_bytes < 4096 ? 4096 : piece_bytes) {
+    if (const char* e = getenv("MK_PGUNZIP_FAIL_ROUND")) fail_round_ = atoi(e);  // (tests: make that round give up)
+  }
 
   // Decode from bit `start_bit` of [base, end) -- a verified block header -- whose preceding text ends
   // with history[0..history_len) (up to 32 KiB).  One round: up to `threads` pieces of `piece_bytes`
@@ -69,6 +71,7 @@ class MkParallelInflate {
     *text = nullptr;
     *text_len = 0;
     *text_crc = mk_crc32(0, nullptr, 0);
+    if (rounds_++ == fail_round_) return BAD_DATA;
     const uint64_t end_bit = (uint64_t)(end - base) * 8;
     const auto t_a = std::chrono::steady_clock::now();
     // ---- 1. piece starts: the verified one, then the first plausible block header after every cut
@@ -275,6 +278,7 @@ class MkParallelInflate {
 
   int threads_;
   size_t piece_;
+  int rounds_ = 0, fail_round_ = -1;
   std::vector<std::unique_ptr<Piece>> piece_buf_;
 };
 
@@ -307,10 +311,45 @@ class MkParallelGunzip {
       hist_.clear();
     }
     uint64_t next_bit = 0;
-    const std::vector<uint8_t> hist(hist_);  // (the round may hand out the buffer the history points into)
     uint32_t round_crc = 0;
-    const MkParallelInflate::Result r = par_.round(base_, end_, bit_, hist.data(), hist.size(), buf, text, len, &next_bit, &round_crc);
-    if (r < 0) return r == MkParallelInflate::TRUNCATED ? TRUNCATED : BAD_DATA;
+    MkParallelInflate::Result r = MkParallelInflate::BAD_DATA;
+    if (!serial_) {
+      const std::vector<uint8_t> hist(hist_);  // (the round may hand out the buffer the history points into)
+      r = par_.round(base_, end_, bit_, hist.data(), hist.size(), buf, text, len, &next_bit, &round_crc);
+      if (r == MkParallelInflate::BAD_DATA) {
+        // Whatever the reason (an implausible ratio, damage, a stream the pieces cannot be cut from): go on
+        // front to back from the last verified block header, with one decoder that keeps its state from call
+        // to call.  If the data is damaged it is this decoder that says so.
+        serial_ = true;
+        ++serial_fallbacks;
+        seq_.reset_at_bit(base_, end_, bit_);
+        if (!sbuf_.reserve(MkParallelInflate::WINDOW + SERIAL_STEP)) return BAD_DATA;
+        memset(sbuf_.p, 0, MkParallelInflate::WINDOW);
+        if (!hist_.empty()) memcpy(sbuf_.p + MkParallelInflate::WINDOW - hist_.size(), hist_.data(), hist_.size());
+        slen_ = 0;
+      } else if (r < 0) {
+        return TRUNCATED;
+      }
+    }
+    if (serial_) {
+      // slide: the last 32 KiB written become the window in front of the next stretch
+      uint8_t* const w = sbuf_.p;
+      if (slen_ >= MkParallelInflate::WINDOW) memcpy(w, w + slen_, MkParallelInflate::WINDOW);  // (regions cannot overlap: slen_ >= WINDOW)
+      else if (slen_) memmove(w, w + slen_, MkParallelInflate::WINDOW);
+      size_t got = 0;
+      const MkInflate::Status st = seq_.run(w + MkParallelInflate::WINDOW, w + MkParallelInflate::WINDOW + SERIAL_STEP, w, &got);
+      slen_ = got;
+      if (st == MkInflate::BAD_DATA) return BAD_DATA;
+      if (st == MkInflate::TRUNCATED) return TRUNCATED;
+      if (!buf.reserve(got + 8)) return BAD_DATA;
+      memcpy(buf.p, w + MkParallelInflate::WINDOW, got);
+      *text = buf.p;
+      *len = got;
+      round_crc = mk_crc32(0, buf.p, got);
+      r = st == MkInflate::STREAM_END ? MkParallelInflate::STREAM_END : MkParallelInflate::MORE;
+      next_bit = st == MkInflate::STREAM_END ? (uint64_t)(seq_.input_pos() - base_) * 8 : bit_;
+      if (st == MkInflate::STREAM_END) serial_ = false;  // the next member gets the pieces again
+    }
     const uint8_t* out = *text;
     const size_t n = *len;
     crc_ = (uint32_t)crc32_combine(crc_, round_crc, (z_off_t)n);
@@ -347,6 +386,15 @@ class MkParallelGunzip {
   uint64_t len_ = 0;
   int members_ = 0;
   std::vector<uint8_t> hist_;
+  // front-to-back continuation (see next())
+  static constexpr size_t SERIAL_STEP = (size_t)16 << 20;
+  bool serial_ = false;
+  MkInflate seq_;
+  MkRawBuf<uint8_t> sbuf_;
+  size_t slen_ = 0;
+
+ public:
+  int serial_fallbacks = 0;
 };
 
 #endif

@@ -157,3 +157,19 @@ def test_parallel_decoder_members_and_damage():
             assert native.gunzip_parallel(bytes(bad), len(a) + 500_000, rng.choice([2, 5]), 4096)[0] == a
         except native.MercatHipError:
             pass
+
+
+@pytest.mark.parametrize("fail_round", [0, 1, 3])
+def test_parallel_decoder_continues_front_to_back_when_a_round_gives_up(monkeypatch, fail_round):
+    """Whatever makes a round of pieces give up (here: forced), decoding goes on front to back from the last
+    verified block header, through member ends, and the next member is cut into pieces again."""
+    monkeypatch.setenv("MK_PGUNZIP_FAIL_ROUND", str(fail_round))
+    a, b = TEXTS["reads"] * 5, TEXTS["text"] + TEXTS["far"]
+    gz = _gz(a, 6, memlevel=3) + _gz(b, 1)
+    for threads, piece in ((3, 4096), (2, 65536)):
+        got, members = native.gunzip_parallel(gz, len(a) + len(b), threads, piece)
+        assert got == a + b and members == 2, (fail_round, threads, piece)
+    bad = bytearray(gz)
+    bad[len(gz) // 3] ^= 0x21
+    with pytest.raises(native.MercatHipError):
+        native.gunzip_parallel(bytes(bad), len(a) + len(b) + 300_000, 3, 4096)
