@@ -899,18 +899,12 @@ extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const u
   MK_HIP(hipSetDevice(c->device));
   int rc;
   MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
-  if (c->mode == MK_MODE_HASH64) {
-    // the all-ones key travels as an ordinary pair; peel it off on the host side of the call
-    std::vector<u64> last(2);
-    MK_HIP(hipMemcpyAsync(&last[0], d_keys + rows - 1, 8, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipMemcpyAsync(&last[1], d_counts + rows - 1, 8, hipMemcpyDeviceToHost, c->stream));
-    MK_HIP(hipStreamSynchronize(c->stream));
-    if (last[0] == MK_EMPTY) { c->run_side += last[1]; rows -= 1; }
-    if ((rc = grow_run64(c, c->run_rows + rows)) != MK_OK) return rc;
-  }
+  // (the all-ones key travels as an ordinary pair, anywhere in the rows: the kernel sets it aside)
+  if (c->mode == MK_MODE_HASH64 && (rc = grow_run64(c, c->run_rows + rows)) != MK_OK) return rc;
   if ((rc = mk_launch_import_pairs(c, d_keys, d_counts, rows)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
   c->run_rows += (size_t)c->h_info->new_rows;
+  if (c->mode == MK_MODE_HASH64) c->run_side += c->h_info->side;
   return MK_OK;
 }
 

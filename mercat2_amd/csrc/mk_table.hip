@@ -84,11 +84,18 @@ __global__ void mk_accumulate64_k(const MkSlot* __restrict__ from, size_t slots,
   block_add(new_rows, fresh);
 }
 
+// The all-ones key (32 x 'T') cannot live in the table (it is the free-slot mark): wherever it stands in
+// the rows -- rows received from several peers are a concatenation of sorted segments -- its count goes
+// to *side (the context keeps that one key beside the table).
 __global__ void mk_import_pairs_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
-                                  MkSlot* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows) {
+                                  MkSlot* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows, u64* __restrict__ side) {
   u64 fresh = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)
-    if (cnts[i]) fresh += upsert64(run, run_mask, keys[i], cnts[i]) ? 1 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+    const u64 key = keys[i], cnt = cnts[i];
+    if (!cnt) continue;
+    if (key == MK_EMPTY) atomicAdd(side, cnt);
+    else fresh += upsert64(run, run_mask, key, cnt) ? 1 : 0;
+  }
   block_add(new_rows, fresh);
 }
 
@@ -333,7 +340,7 @@ int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_
                        (const u64*)d_counts, rows, (u64*)c->run.p, nbins);
   } else {
     hipLaunchKernelGGL(mk_import_pairs_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
-                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows);
+                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows, &info->side);
   }
   MK_HIP(hipGetLastError());
   return MK_OK;

@@ -375,6 +375,10 @@ class Counter:
     def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
         self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
 
+    def words_per_key(self) -> int:
+        """64-bit words per packed key in export_pairs_device / import_pairs_device (mk_words_per_key)."""
+        return int(self._L.mk_words_per_key(self._h))
+
     def alpha_stats(self) -> dict:
         """Moments of the count column, reduced on the GPU (mk_alpha_stats)."""
         a = AlphaStats()

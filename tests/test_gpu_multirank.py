@@ -26,7 +26,9 @@ def _data():
     from mercat2_amd import native
     reads = native.synth_reads(150_000, 31, 120_000, 150, 32).tobytes()
     odd = read_input("edge_lengths.fa")  # N / IUPAC windows -> by-reference rows cross ranks too
-    return reads + odd
+    # the all-T 32-mer (the packed table's free-slot mark, kept beside the table) in the FIRST chunk, which
+    # rank 0 counts: after the exchange it stands in the middle of the rows the last rank receives
+    return b">polyT\n" + b"T" * 200 + b"\n" + reads + odd
 
 
 def _chunks(data):
@@ -53,7 +55,7 @@ def _worker(rank, port, k, c, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("k,c", [(31, 2), (21, 1)])
+@pytest.mark.parametrize("k,c", [(31, 2), (21, 1), (32, 2)])
 def test_two_ranks_equal_one(k, c):
     from mercat2_amd import native
     data = _data()
