@@ -71,8 +71,9 @@ def cpu_baseline(k, c, genome, gseed, rseed, chunk_reads):
     to the CPU."""
     import multiprocessing as mp
     cores = max(1, min(os.cpu_count() or 1, 16))
-    per = max(1000, chunk_reads // 16)  # the same slice size whatever the core count: ~15 s of work per process
-    jobs = [(genome, gseed, rseed, i * per, per, k, c) for i in range(cores)]
+    per = max(1000, chunk_reads // 16)  # the same slice size whatever the core count (~0.5 GB of dict per process at S2)
+    rounds = 3                          # slices per process, one after the other: ~10-30 s of CPU work per core
+    jobs = [(genome, gseed, rseed, i * per, per, k, c) for i in range(cores * rounds)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         res = pool.map(cpu_sample_worker, jobs)
@@ -81,9 +82,9 @@ def cpu_baseline(k, c, genome, gseed, rseed, chunk_reads):
     busy = sum(r[1] for r in res)
     out = {"value": bases / wall, "unit": "bases/s", "cores": cores, "kind": "port",
            "sample": "reads 0..%d of the benchmark sample (genome %d bp, seeds %d/%d: the head of its first %d-read chunk), "
-                     "%d slices of %d reads x %d bp, one per process, k=%d, c=%d, pure-Python oracle (oracle/cpu_ref.py); "
-                     "per-core rate %.3g bases/s, distinct keys per slice %d"
-                     % (per * cores, genome, gseed, rseed, chunk_reads, cores, per, READ_LEN, k, c, bases / busy, res[0][2] if c <= 1 else -1)}
+                     "%d slices of %d reads x %d bp, %d processes, k=%d, c=%d, pure-Python oracle (oracle/cpu_ref.py); "
+                     "per-core rate %.3g bases/s"
+                     % (per * len(jobs), genome, gseed, rseed, chunk_reads, len(jobs), per, READ_LEN, cores, k, c, bases / busy)}
     cal = ROOT / "profiles" / "round2_calibration.json"
     if cal.exists():
         j = json.loads(cal.read_text())
@@ -113,7 +114,10 @@ def launch_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    # exactly one line on stdout: rank 0's JSON (whatever else a library printed there goes to stderr)
+    lines = out.decode().splitlines()
+    for ln in lines:
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
     if bad:

@@ -18,6 +18,12 @@ Outputs
   tsv/*                    full TSV text of a few small cases and the reference's own
                            committed count tables (results/2023-11-29/...)
   chunks.json              reference Chunker cut points (byte offsets) + per-chunk sha256
+  expected_big.json        the other four genomes / three proteomes of data/5-genomes-* (BASELINE
+                           configs 1 and 4 name all five): per case rows, sum, sha256 of the TSV text
+                           and sha256 of the raw key bytes / little-endian u64 counts (cheap to check
+                           from arrays at millions of rows)
+  clean.json               sha256 / size of the decompressed text of the reference's committed
+                           clean/*_clean.fna.gz (its removeN outputs) for the five genomes
 """
 import gzip
 import hashlib
@@ -163,6 +169,14 @@ def main():
         "RW1_fgs.faa.gz": "results/2023-11-29/fna-5genomes_gz-10/fgs/RW1.faa.gz",
         "DJ_pro.faa.gz": "data/5-genomes-faa_gz/DJ_pro.faa.gz",
         "Test_R1.fna.gz": "results/2023-11-29/test-qc_gz/clean/Test_R1.fna.gz",
+        # the rest of data/5-genomes-fna_gz and data/5-genomes-faa_gz (BASELINE configs 1 and 4)
+        "DJ.fna.gz": "data/5-genomes-fna_gz/DJ.fna.gz",
+        "GIC31.fna.gz": "data/5-genomes-fna_gz/GIC31.fna.gz",
+        "RW2.fna.gz": "data/5-genomes-fna_gz/RW2.fna.gz",
+        "Rleg.fna.gz": "data/5-genomes-fna_gz/Rleg.fna.gz",
+        "GIC31_pro.faa.gz": "data/5-genomes-faa_gz/GIC31_pro.faa.gz",
+        "RW2_pro.faa.gz": "data/5-genomes-faa_gz/RW2_pro.faa.gz",
+        "Rleg_pro.faa.gz": "data/5-genomes-faa_gz/Rleg_pro.faa.gz",
     }
     for dst, src in copies.items():
         shutil.copyfile(REF / src, INPUTS / dst)
@@ -260,11 +274,58 @@ def main():
     chunks["DJ_pro.faa.gz|1M"]["committed_sha256"] = [hashlib.sha256(p.read_bytes()).hexdigest() for p in ref_chunks]
     assert chunks["DJ_pro.faa.gz|1M"]["committed_sha256"] == chunks["DJ_pro.faa.gz|1M"]["sha256"]
 
+    # ---- the big files: all five genomes at k=3/c=10 (config 1), k=31/c=1 and c=10, k=5/c=10 on the cleaned
+    #      twin where the reference committed the table; proteomes at k=3/c=10 (config 4) and k=5/c=10
+    import numpy as np
+    big = {}
+
+    def big_case(fname, base, k, c, table):
+        keys = sorted(table)
+        d = digest(base, table)
+        d["keys_sha256"] = hashlib.sha256("".join(keys).encode()).hexdigest()
+        d["counts_sha256"] = hashlib.sha256(np.array([table[x] for x in keys], dtype="<u8").tobytes()).hexdigest()
+        big["%s|k%d|c%d" % (fname, k, c)] = dict(input=fname, basename=base, k=k, c=c, **d)
+
+    for fname in ["DJ.fna.gz", "GIC31.fna.gz", "RW1.fna.gz", "RW2.fna.gz", "Rleg.fna.gz"]:
+        base = basename_of(fname)
+        raw = kmers.find_kmers(INPUTS / fname, 3, 0)
+        big_case(fname, base, 3, 10, {a: b for a, b in raw.items() if b >= 10})
+        raw = kmers.find_kmers(INPUTS / fname, 31, 0)
+        for c in (1, 10):
+            big_case(fname, base, 31, c, {a: b for a, b in raw.items() if b >= c})
+        del raw
+    for fname in ["DJ_pro.faa.gz", "GIC31_pro.faa.gz", "RW1_pro.faa.gz", "RW2_pro.faa.gz", "Rleg_pro.faa.gz"]:
+        base = basename_of(fname)
+        for k in (3, 5):
+            big_case(fname, base, k, 10, kmers.find_kmers(INPUTS / fname, k, 10))
+        # the reference's committed table of the same run (results/run-tests.sh: k=5, -c 10, -s 10: unchunked)
+        want = (REF / "results/2023-11-29/faa-5genomes-10/tsv_protein" / (base + "_counts.tsv")).read_text()
+        assert hashlib.sha256(want.encode()).hexdigest() == big["%s|k5|c10" % fname]["sha256"], fname
+    # SURVEY.md 8(c) known answers (first 16 hex digits of the TSV sha256)
+    known = {"DJ.fna.gz|k3|c10": "c6eadaec2188bb43", "GIC31.fna.gz|k3|c10": "0e68d1e690114f80", "RW1.fna.gz|k3|c10": "3ac4bb1f9ca6baa1",
+             "RW2.fna.gz|k3|c10": "0fe5a38b181435c3", "Rleg.fna.gz|k3|c10": "4127b01ca65d4e3b", "DJ.fna.gz|k31|c1": "d968c29ebee74951",
+             "GIC31.fna.gz|k31|c1": "59c3181f9a7c39b1", "RW1.fna.gz|k31|c1": "985928da4290698c", "RW2.fna.gz|k31|c1": "1537f3abc37cc482",
+             "Rleg.fna.gz|k31|c1": "ae6becf6677bee2c", "DJ.fna.gz|k31|c10": "a91a92379c42782f", "Rleg.fna.gz|k31|c10": "14840589c294b8b7",
+             "DJ_pro.faa.gz|k3|c10": "2b68e8c6b8a5e68e", "GIC31_pro.faa.gz|k3|c10": "2ee2bd8d48ca4757", "RW1_pro.faa.gz|k3|c10": "e98c90e9c61c7d40",
+             "RW2_pro.faa.gz|k3|c10": "5fe201e30219ce8b", "Rleg_pro.faa.gz|k3|c10": "668ed139decf1723"}
+    for case, head in known.items():
+        assert big[case]["sha256"].startswith(head), (case, big[case]["sha256"])
+    (HERE / "expected_big.json").write_text(json.dumps(big, indent=0, sort_keys=True))
+
+    # ---- the reference's committed removeN outputs (results/2023-11-29/fna-5genomes_gz-10/clean) for the five
+    #      genomes: digest of the decompressed text (RW1_clean.fna.gz is also among the inputs in full)
+    clean = {}
+    for g in ["DJ", "GIC31", "RW1", "RW2", "Rleg"]:
+        text = gzip.open(REF / "results/2023-11-29/fna-5genomes_gz-10/clean" / (g + "_clean.fna.gz"), "rb").read()
+        clean[g + ".fna.gz"] = {"clean_name": g + "_clean.fna.gz", "bytes": len(text), "sha256": hashlib.sha256(text).hexdigest(),
+                                "lines": text.count(b"\n")}
+    (HERE / "clean.json").write_text(json.dumps(clean, indent=1, sort_keys=True))
+
     h2b = {s: chunker.human2bytes(s) for s in ["0 B", "1 K", "1 M", "1 Gi", "1 tera", "0.5kilo", "0.1  byte", "1 k", "100M", "1M", "10M", "0M", "1.5G"]}
 
     (HERE / "expected.json").write_text(json.dumps(expected, indent=0, sort_keys=True))
     (HERE / "chunks.json").write_text(json.dumps({"chunks": chunks, "human2bytes": h2b, "committed_tables": committed}, indent=1, sort_keys=True))
-    print("cases:", len(expected), "chunk cases:", len(chunks))
+    print("cases:", len(expected), "big cases:", len(big), "chunk cases:", len(chunks))
 
 
 if __name__ == "__main__":

@@ -59,6 +59,43 @@ def test_golden_matrix(fname, cases):
         assert got == {k: case[k] for k in ("rows", "sum", "sha256")}, (fname, case["k"], case["c"], mode)
 
 
+BIG = json.loads((GOLDEN / "expected_big.json").read_text())
+
+
+def _big_grouped():
+    groups = {}
+    for case in BIG.values():
+        groups.setdefault(case["input"], []).append(case)
+    return sorted(groups.items())
+
+
+@pytest.mark.parametrize("fname,cases", _big_grouped(), ids=[g[0] for g in _big_grouped()])
+def test_all_five_genomes_and_proteomes(fname, cases, tmp_path):
+    """BASELINE configs 1 and 4 on every file of data/5-genomes-fna_gz / 5-genomes-faa_gz: k=3 -c 10, and for
+    the genomes k=31 at -c 1 (up to 7.7 M rows) and -c 10 (0 rows = no TSV for three of them); the TSV the
+    native writer produces must be the reference's byte for byte (sha256), the arrays of mk_export too."""
+    data = read_input(fname)
+    for case in sorted(cases, key=lambda c: (c["k"], c["c"])):
+        out = tmp_path / ("%s_k%d_c%d.tsv" % (case["basename"], case["k"], case["c"]))
+        with native.Counter(case["k"], alphabet_for(fname)) as ctx:
+            ctx.count_chunk(data, case["c"])
+            rows = ctx.write_tsv(out, case["basename"])
+            kmers, counts = ctx.export()
+        assert rows == case["rows"], (fname, case["k"], case["c"])
+        if rows:
+            h = hashlib.sha256()
+            with open(out, "rb") as f:
+                for block in iter(lambda: f.read(1 << 24), b""):
+                    h.update(block)
+            assert h.hexdigest() == case["sha256"], (fname, case["k"], case["c"])
+            out.unlink()
+        else:
+            assert not out.exists()  # bin/mercat2.py:135-137
+        assert int(counts.sum()) == case["sum"]
+        assert hashlib.sha256(kmers.tobytes()).hexdigest() == case["keys_sha256"]
+        assert hashlib.sha256(counts.astype("<u8").tobytes()).hexdigest() == case["counts_sha256"]
+
+
 @pytest.mark.parametrize("alphabet", [native.ALPHABET_RAW, native.ALPHABET_NT2, native.ALPHABET_AA5],
                          ids=["raw", "nt2", "aa5"])
 def test_any_alphabet_gives_the_same_answer(alphabet):
