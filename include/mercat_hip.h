@@ -53,8 +53,8 @@ typedef struct mk_stats_t {
   uint64_t survivors;      /* chunk-table entries that passed their chunk's min_count       */
   uint64_t rows;           /* distinct k-mers now in the running (merged) table             */
   uint64_t table_slots;    /* slots (or dense bins) of the chunk table of the last chunk    */
-  int32_t mode;            /* 0 dense-LDS, 1 hash64 (packed keys), 2 ref128 (33..64-mers: by reference,
-                              packed 128-bit hashing/compare), 3 by-reference on bytes only      */
+  int32_t mode;            /* 0 dense-LDS, 1 hash64 (one-word packed keys), 2 hash128 (nucleotide 33..64-mers:
+                              two-word packed keys), 3 by-reference on bytes only                 */
   int32_t profiled;        /* 1 when per-kernel HIP-event timing is on (mk_set_profiling)   */
   /* HIP-event time per kernel family, milliseconds, and launches (only when profiled) */
   double ms_parse, ms_pack, ms_count, ms_exotic, ms_filter, ms_export;
@@ -162,10 +162,13 @@ int mk_trim(mk_ctx* ctx);
 
 /* ---- multi-GPU merge plumbing (replaces ray.get + dict sum across workers) -------------- */
 /* Packed-key view of the running table for exchange over RCCL: *rows entries sorted by key
- * into caller-provided DEVICE buffers (words_per_key = 1 for hash64/dense, 2 for hash128).
+ * into caller-provided DEVICE buffers.  d_keys holds mk_words_per_key(ctx) 64-bit words per row,
+ * row after row (1 for dense/hash64; 2 for hash128: {hi, lo}, hi = bases 0..31, lo = the rest,
+ * both left-aligned, so (hi, lo) order is the byte order of the k-mer text); cap counts rows.
  * By-reference (exotic) rows are exchanged through mk_export_exotic / mk_import_exotic. */
 int mk_export_pairs_device(mk_ctx* ctx, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows);
-/* insert-add (key,count) pairs from DEVICE buffers into the running table. */
+/* insert-add (key,count) pairs from DEVICE buffers into the running table (same layout; the same key
+ * may come more than once, e.g. rows received from several ranks). */
 int mk_import_pairs_device(mk_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
 int mk_export_exotic(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t cap, size_t* rows);
 int mk_import_exotic(mk_ctx* ctx, const uint8_t* kmers, const uint64_t* counts, size_t rows);
@@ -174,6 +177,11 @@ int mk_words_per_key(const mk_ctx* ctx);
  * canonical mode); src is left unchanged.  Lets a host deal the chunks of one sample to several
  * contexts (= HIP streams) that count concurrently and sum them at the end, on the device. */
 int mk_merge_from(mk_ctx* dst, mk_ctx* src);
+
+/* Drop the rows of the running table whose count is below min_count.  For a sample that is ONE chunk
+ * (one filter unit, lib/mercat2_kmers.py:73-76) but was counted in pieces without a filter -- its records
+ * split over several GPUs -- and merged: the filter comes after the merge. */
+int mk_filter_min(mk_ctx* ctx, uint64_t min_count);
 
 /* ---- statistics / profiling ----------------------------------------------------------- */
 int mk_set_profiling(mk_ctx* ctx, int on);
@@ -203,6 +211,22 @@ int mk_gunzip_parallel(const uint8_t* gz, size_t n, uint8_t* out, size_t cap, in
                        size_t* written, int* members);
 /* zlib's crc32(seed, p, n) as the gzip reader computes it (carry-less multiplies; csrc/mk_crc32.h). */
 uint32_t mk_crc32_of(const uint8_t* p, size_t n, uint32_t seed);
+/* removeN (lib/mercat2_fasta.py:53-119 with split_sequenceN :21-49), the rewrite MerCat2 applies to every
+ * nucleotide FASTA before counting (bin/mercat2.py:239-244): records holding 'N' are cut at every run of N
+ * into ">{name}_{i} {info}" pieces re-wrapped at 80 columns, the others are written back line by line;
+ * toupper != 0 upper-cases sequence lines on output.  text = the (decompressed) file; *out receives a
+ * malloc'ed buffer with the cleaned text (release it with mk_free), st the figures GC content is made of.
+ * MK_ERR_RANGE: a record to be split has an empty header (the reference raises IndexError).  When a
+ * sequence to be split holds a blank, tab or hyphen (textwrap would treat it as a word break) nothing is
+ * produced and st->unsupported_record names the record: the Python host layer then rewrites that file. */
+typedef struct mk_clean_stats_t {
+  uint64_t gc_count;      /* 'G' + 'C' as the reference counts them (header lines of split records included) */
+  uint64_t total_length;  /* the length it divides by: GC content = 100 * gc_count / total_length            */
+  uint64_t records, split_records, pieces, n_runs;
+  int64_t unsupported_record; /* -1, or the index of the first record this function does not rewrite */
+} mk_clean_stats_t;
+int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t** out, size_t* out_len, mk_clean_stats_t* st);
+void mk_free(void* p);
 /* Deterministic synthetic reads: genome of `genome_len` iid ACGT from
  * splitmix64(genome_seed); `reads` reads of `read_len` from uniform starts, reverse-complemented
  * on a coin flip, per-base substitution with probability sub_ppm/1e6, all from

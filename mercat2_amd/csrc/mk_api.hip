@@ -104,7 +104,7 @@ extern "C" const char* mk_version(void) { return "mercat_hip 0.1 (gfx950)"; }
 
 extern "C" const char* mk_last_error(const mk_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 
-extern "C" int mk_words_per_key(const mk_ctx* c) { return c ? 1 : 0; }
+extern "C" int mk_words_per_key(const mk_ctx* c) { return c ? (c->mode == MK_MODE_HASH128 ? 2 : 1) : 0; }
 
 static int pull_info(mk_ctx* c) {
   MK_HIP(hipMemcpyAsync(c->h_info, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
@@ -176,7 +176,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
-                     &c->run_ref, &c->arena, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2};
+                     &c->run_ref, &c->arena, &c->run128, &c->ex128, &c->ex128_out, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->ingest_ring) (void)hipHostFree(c->ingest_ring);
@@ -197,8 +197,10 @@ extern "C" int mk_reset(mk_ctx* c) {
     int rc = mk_launch_clear_slots(c, (MkSlot*)c->run_ref.p, c->run_ref_slots);
     if (rc) return rc;
   }
+  if (c->run128_slots) MK_HIP(hipMemsetAsync(c->run128.p, 0, c->run128_slots * sizeof(MkSlot128), c->stream));
   c->run_rows = 0;
   c->run_ref_rows = 0;
+  c->run128_rows = 0;
   c->run_side = 0;
   c->in_chunk = false;
   c->raw_len = 0;
@@ -210,8 +212,8 @@ extern "C" int mk_set_canonical(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;
   if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_canonical: only the nucleotide alphabet has a reverse complement"; return MK_ERR_ARG; }
   if (on && c->mode != MK_MODE_DENSE && c->mode != MK_MODE_HASH64) { c->err = "mk_set_canonical: canonical counting is implemented for k <= 32"; return MK_ERR_ARG; }
-  if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run_side || c->st.chunks) {
-    if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run_side || c->in_chunk)) {
+  if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->st.chunks) {
+    if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->in_chunk)) {
       c->err = "mk_set_canonical: the running table already holds rows counted in the other mode (mk_reset first)";
       return MK_ERR_STATE;
     }
@@ -278,6 +280,21 @@ static int grow_run64(mk_ctx* c, size_t need_rows) {
   buf_free(c->run);
   c->run = nb;
   c->run_slots = slots;
+  return MK_OK;
+}
+
+static int grow_run128(mk_ctx* c, size_t need_rows) {
+  if (2 * need_rows <= c->run128_slots) return MK_OK;
+  const size_t slots = pow2_at_least(4 * need_rows);
+  MkDevBuf nb;
+  int rc = mk_buf_reserve(c, nb, slots * sizeof(MkSlot128));
+  if (rc) return rc;
+  MK_HIP(hipMemsetAsync(nb.p, 0, slots * sizeof(MkSlot128), c->stream));
+  if (c->run128_slots && (rc = mk_launch_rehash128(c, (const MkSlot128*)c->run128.p, c->run128_slots, (MkSlot128*)nb.p, slots)) != MK_OK) return rc;
+  MK_HIP(hipStreamSynchronize(c->stream));
+  buf_free(c->run128);
+  c->run128 = nb;
+  c->run128_slots = slots;
   return MK_OK;
 }
 
@@ -399,16 +416,6 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if (rc) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
   }
-  // the two-word kernels report in the one-word path's fields (they may have to be discarded on their own):
-  // fold them into the by-reference totals of the host copy after every read-back
-  auto fold_sk2 = [&]() {
-    if (!sk2) return;
-    c->h_info->exotic += c->h_info->windows;
-    c->h_info->survivors_ref += c->h_info->survivors;
-    c->h_info->windows = 0;
-    c->h_info->survivors = 0;
-  };
-  fold_sk2();
   if (c->h_info->errors) {
     c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";
     return MK_ERR_RANGE;
@@ -417,12 +424,16 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = grow_run64(c, c->run_rows + (size_t)c->h_info->survivors)) != MK_OK) return rc;
   if (c->h_info->survivors_ref)
     if ((rc = grow_run_ref(c, c->run_ref_rows + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
-  if (sk2 && c->surv_regions == 2 && seq_len) {
+  // two-word keys: survivors of the partitioned kernel, or (unpartitioned path) of the by-reference chunk table,
+  // whose clean rows are packed on their way into the running table
+  if (c->mode == MK_MODE_HASH128 && (c->h_info->survivors || c->h_info->survivors_ref))
+    if ((rc = grow_run128(c, c->run128_rows + (size_t)c->h_info->survivors + (size_t)c->h_info->survivors_ref)) != MK_OK) return rc;
+  if (sk2 && c->surv_regions == 2 && seq_len && c->h_info->survivors) {
     const size_t p1 = (size_t)1 << c->p1_log2;
     const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
     mk_prof_begin(c, MK_K_FILTER);
-    rc = mk_launch_import_ref128_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_keys2.p,
-                                         (const uint64_t*)c->surv_cnts.p, meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+    rc = mk_launch_import128_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_keys2.p,
+                                     (const uint64_t*)c->surv_cnts.p, meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
     mk_prof_end(c);
     if (rc) return rc;
   }
@@ -441,12 +452,12 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   }
   if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;
   if ((rc = pull_info(c)) != MK_OK) return rc;
-  fold_sk2();
-  c->run_rows += (size_t)c->h_info->new_rows;
+  if (c->mode == MK_MODE_HASH128) c->run128_rows += (size_t)c->h_info->new_rows;
+  else c->run_rows += (size_t)c->h_info->new_rows;
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
   if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
-  if (sk2 && c->h_info->distinct) c->dup_hint = (double)c->h_info->exotic / (double)c->h_info->distinct;
+  if (sk2 && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
   if ((partitioned || sk2) && c->h_info->records)
     c->nk_hint = (double)(c->h_info->windows + c->h_info->exotic) / (double)c->h_info->records;
 
@@ -488,7 +499,9 @@ extern "C" int mk_count_device(mk_ctx* c, const uint8_t* d_text, size_t n, uint6
 
 // --------------------------------------------------------------------------------- export
 struct ExportView {
-  std::vector<u64> pkeys, pcnts;     // packed rows, sorted by key
+  std::vector<u64> pkeys, pcnts;     // packed rows, sorted by key (two-word keys: pkeys holds {hi, lo} pairs)
+  int words = 1;                     // 64-bit words per packed key
+  size_t packed_rows() const { return pcnts.size(); }
   std::vector<uint8_t> rstr;         // by-reference rows: k bytes each, arena order
   std::vector<u64> rcnt;             // counts in arena order
   std::vector<u64> rorder;           // arena rows sorted by string
@@ -562,6 +575,47 @@ static int gather_packed(mk_ctx* c, ExportView& v, u64* d_keys_out, u64* d_cnts_
       rows += 1;
     }
   }
+  else if (c->mode == MK_MODE_HASH128) {
+    v.words = 2;
+    rows = c->run128_rows;
+    if (!to_host && rows > cap) { c->err = "export: device buffers too small"; return MK_ERR_RANGE; }
+    if (rows) {
+      mk_prof_begin(c, MK_K_EXPORT);
+      // compacted {hi | lo | count} + 4 n words of sort scratch
+      if ((rc = mk_buf_reserve(c, c->ex128, 7 * rows * 8 + 64)) != MK_OK) return rc;
+      u64* hi = (u64*)c->ex128.p;
+      u64* lo = hi + rows;
+      u64* cn = lo + rows;
+      u64* scratch = cn + rows;
+      u64* d_cursor = (u64*)((char*)c->info.p + sizeof(MkChunkInfo));
+      MK_HIP(hipMemsetAsync(d_cursor, 0, 8, c->stream));
+      if ((rc = mk_launch_compact128(c, (const MkSlot128*)c->run128.p, c->run128_slots, (uint64_t*)hi, (uint64_t*)lo,
+                                     (uint64_t*)cn, rows, (uint64_t*)d_cursor)) != MK_OK) return rc;
+      u64* ok = d_keys_out;
+      u64* oc = d_cnts_out;
+      if (to_host) {
+        if ((rc = mk_buf_reserve(c, c->ex128_out, 3 * rows * 8 + 64)) != MK_OK) return rc;
+        ok = (u64*)c->ex128_out.p;
+        oc = ok + 2 * rows;
+      }
+      if ((rc = mk_sort_pairs128(c, (const uint64_t*)hi, (const uint64_t*)lo, (const uint64_t*)cn, rows, 2 * (c->k - 32),
+                                 (uint64_t*)scratch, (uint64_t*)ok, (uint64_t*)oc)) != MK_OK) return rc;
+      mk_prof_end(c);
+      if (to_host) {
+        v.pkeys.resize(2 * rows);
+        v.pcnts.resize(rows);
+        MK_HIP(hipMemcpyAsync(v.pkeys.data(), ok, 2 * rows * 8, hipMemcpyDeviceToHost, c->stream));
+        MK_HIP(hipMemcpyAsync(v.pcnts.data(), oc, rows * 8, hipMemcpyDeviceToHost, c->stream));
+      }
+      u64 got = 0;
+      MK_HIP(hipMemcpyAsync(&got, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+      MK_HIP(hipStreamSynchronize(c->stream));
+      if (got != rows) {
+        c->err = "export: two-word table holds " + std::to_string(got) + " rows, expected " + std::to_string(rows);
+        return MK_ERR_STATE;
+      }
+    }
+  }
   if (rows_out) *rows_out = rows;
   return MK_OK;
 }
@@ -610,6 +664,8 @@ static int gather_ref(mk_ctx* c, ExportView& v, bool sorted) {
   return MK_OK;
 }
 
+// packed row i of a view -> its k characters
+static inline void decode_row(const mk_ctx* c, const ExportView& v, size_t i, uint8_t* out);
 static inline void decode_key(const mk_ctx* c, u64 key, uint8_t* out) {
   const int k = c->k;
   if (c->alphabet == MK_ALPHABET_NT2) {
@@ -619,16 +675,24 @@ static inline void decode_key(const mk_ctx* c, u64 key, uint8_t* out) {
   }
 }
 
+static inline void decode_row(const mk_ctx* c, const ExportView& v, size_t i, uint8_t* out) {
+  if (v.words == 1) { decode_key(c, v.pkeys[i], out); return; }
+  const u64 hi = v.pkeys[2 * i], lo = v.pkeys[2 * i + 1];  // left-aligned: base j < 32 in hi, the rest in lo
+  const int k = c->k;
+  for (int j = 0; j < 32; ++j) out[j] = "ACGT"[(hi >> (62 - 2 * j)) & 3];
+  for (int j = 32; j < k; ++j) out[j] = "ACGT"[(lo >> (62 - 2 * (j - 32))) & 3];
+}
+
 // Visit every row in sorted(str) order: a 2-way merge of the packed rows (decoded on the fly)
 // and the by-reference rows.
 template <class F>
 static void merged_rows(const mk_ctx* c, const ExportView& v, F&& f) {
-  const size_t k = (size_t)c->k, np = v.pkeys.size(), nr = v.rorder.size();
+  const size_t k = (size_t)c->k, np = v.packed_rows(), nr = v.rorder.size();
   std::vector<uint8_t> buf(k ? k : 1);
   size_t i = 0, j = 0;
   bool have = false;
   while (i < np || j < nr) {
-    if (i < np && !have) { decode_key(c, v.pkeys[i], buf.data()); have = true; }
+    if (i < np && !have) { decode_row(c, v, i, buf.data()); have = true; }
     bool take_packed;
     if (i >= np) take_packed = false;
     else if (j >= nr) take_packed = true;
@@ -652,9 +716,9 @@ extern "C" int mk_export_size(mk_ctx* c, size_t* rows) {
     MK_HIP(hipSetDevice(c->device));
     int rc = gather_packed(c, v, nullptr, nullptr, 0, nullptr, true);
     if (rc) return rc;
-    *rows = v.pkeys.size() + c->run_ref_rows;
+    *rows = v.packed_rows() + c->run_ref_rows;
   } else {
-    *rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows;
+    *rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows + c->run128_rows;
   }
   c->st.rows = *rows;
   return MK_OK;
@@ -665,7 +729,7 @@ extern "C" int mk_export(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t row
   ExportView v;
   int rc = build_view(c, v);
   if (rc) return rc;
-  const size_t rows = v.pkeys.size() + v.rorder.size();
+  const size_t rows = v.packed_rows() + v.rorder.size();
   if (rows > rows_cap) { c->err = "mk_export: rows_cap too small"; return MK_ERR_RANGE; }
   if (rows && (!kmers || !counts)) { c->err = "mk_export: NULL output"; return MK_ERR_ARG; }
   const size_t k = (size_t)c->k;
@@ -683,7 +747,7 @@ extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, s
   ExportView v;
   int rc = build_view(c, v);
   if (rc) return rc;
-  const size_t rows = v.pkeys.size() + v.rorder.size();
+  const size_t rows = v.packed_rows() + v.rorder.size();
   if (rows_out) *rows_out = rows;
   if (!rows) return MK_OK;  // bin/mercat2.py:135-137: no file when nothing survives
   FILE* f = fopen(path, "wb");
@@ -725,10 +789,10 @@ struct RowIter {  // the rows of one sample in sorted(str) order
   u64 cnt = 0;
   RowIter(const mk_ctx* c_, const ExportView* v_) : c(c_), v(v_), buf((size_t)c_->k + 1) {}
   bool next() {
-    const size_t k = (size_t)c->k, np = v->pkeys.size(), nr = v->rorder.size();
+    const size_t k = (size_t)c->k, np = v->packed_rows(), nr = v->rorder.size();
     if (i >= np && j >= nr) { cur = nullptr; return false; }
     bool take_packed;
-    if (i < np) decode_key(c, v->pkeys[i], buf.data());
+    if (i < np) decode_row(c, *v, i, buf.data());
     if (i >= np) take_packed = false;
     else if (j >= nr) take_packed = true;
     else take_packed = memcmp(buf.data(), v->rstr.data() + v->rorder[j] * k, k) < 0;
@@ -874,7 +938,7 @@ extern "C" int mk_trim(mk_ctx* c) {
   MK_HIP(hipSetDevice(c->device));
   MK_HIP(hipStreamSynchronize(c->stream));
   MkDevBuf* scratch[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->ctab, &c->rtab_chunk, &c->part,
-                         &c->surv_keys, &c->surv_cnts, &c->surv_keys2, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp};
+                         &c->surv_keys, &c->surv_cnts, &c->surv_keys2, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->ex128, &c->ex128_out};
   for (auto* b : scratch)
     if (!(b == &c->ctab && c->mode == MK_MODE_DENSE)) buf_free(*b);  // the dense bins are allocated once, at mk_create
   if (c->mode != MK_MODE_DENSE) c->ctab_slots = 0;
@@ -886,7 +950,7 @@ extern "C" int mk_trim(mk_ctx* c) {
 // ------------------------------------------------------------------- multi-GPU plumbing
 extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;
-  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) { *rows = 0; return MK_OK; }  // rows travel as text (mk_export_exotic)
+  if (c->mode == MK_MODE_BYREF) { *rows = 0; return MK_OK; }  // rows travel as text (mk_export_exotic)
   MK_HIP(hipSetDevice(c->device));
   ExportView v;
   return gather_packed(c, v, (u64*)d_keys, (u64*)d_counts, cap, rows, false);
@@ -895,10 +959,17 @@ extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_c
 extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
   if (!c) return MK_ERR_ARG;
   if (!rows) return MK_OK;
-  if (c->mode == MK_MODE_BYREF || c->mode == MK_MODE_HASH128) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
+  if (c->mode == MK_MODE_BYREF) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(c->device));
   int rc;
   MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if (c->mode == MK_MODE_HASH128) {  // d_keys: {hi, lo} per row
+    if ((rc = grow_run128(c, c->run128_rows + rows)) != MK_OK) return rc;
+    if ((rc = mk_launch_import128_pairs(c, d_keys, d_counts, rows)) != MK_OK) return rc;
+    if ((rc = pull_info(c)) != MK_OK) return rc;
+    c->run128_rows += (size_t)c->h_info->new_rows;
+    return MK_OK;
+  }
   // (the all-ones key travels as an ordinary pair, anywhere in the rows: the kernel sets it aside)
   if (c->mode == MK_MODE_HASH64 && (rc = grow_run64(c, c->run_rows + rows)) != MK_OK) return rc;
   if ((rc = mk_launch_import_pairs(c, d_keys, d_counts, rows)) != MK_OK) return rc;
@@ -944,6 +1015,62 @@ extern "C" int mk_import_exotic(mk_ctx* c, const uint8_t* kmers, const uint64_t*
   return MK_OK;
 }
 
+// Drop every row of the running table whose count is below min_count: the filter of a sample that is ONE
+// chunk but was counted in pieces (record ranges on several GPUs, unfiltered) and merged
+// (lib/mercat2_kmers.py:73-76 applies it once per file).
+extern "C" int mk_filter_min(mk_ctx* c, uint64_t min_count) {
+  if (!c) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_filter_min: a chunk is open"; return MK_ERR_STATE; }
+  if (min_count <= 1) return MK_OK;
+  MK_HIP(hipSetDevice(c->device));
+  int rc;
+  u64* d_kept = (u64*)((char*)c->info.p + sizeof(MkChunkInfo));
+  u64 kept = 0;
+  if (c->mode == MK_MODE_DENSE) {
+    if ((rc = mk_launch_refilter_dense(c, (uint64_t*)c->run.p, c->run_slots, min_count)) != MK_OK) return rc;
+  } else if (c->mode == MK_MODE_HASH64 && c->run_slots) {
+    MkDevBuf nb;
+    if ((rc = mk_buf_reserve(c, nb, c->run_slots * sizeof(MkSlot))) != MK_OK) return rc;
+    if ((rc = mk_launch_clear_slots(c, (MkSlot*)nb.p, c->run_slots)) != MK_OK) return rc;
+    MK_HIP(hipMemsetAsync(d_kept, 0, 8, c->stream));
+    if ((rc = mk_launch_refilter64(c, (const MkSlot*)c->run.p, (MkSlot*)nb.p, c->run_slots, min_count, (uint64_t*)d_kept)) != MK_OK) return rc;
+    MK_HIP(hipMemcpyAsync(&kept, d_kept, 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    buf_free(c->run);
+    c->run = nb;
+    c->run_rows = (size_t)kept;
+    if (c->run_side < min_count) c->run_side = 0;
+  } else if (c->mode == MK_MODE_HASH128 && c->run128_slots) {
+    MkDevBuf nb;
+    if ((rc = mk_buf_reserve(c, nb, c->run128_slots * sizeof(MkSlot128))) != MK_OK) return rc;
+    MK_HIP(hipMemsetAsync(nb.p, 0, c->run128_slots * sizeof(MkSlot128), c->stream));
+    MK_HIP(hipMemsetAsync(d_kept, 0, 8, c->stream));
+    if ((rc = mk_launch_refilter128(c, (const MkSlot128*)c->run128.p, (MkSlot128*)nb.p, c->run128_slots, min_count, (uint64_t*)d_kept)) != MK_OK) return rc;
+    MK_HIP(hipMemcpyAsync(&kept, d_kept, 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    buf_free(c->run128);
+    c->run128 = nb;
+    c->run128_rows = (size_t)kept;
+  }
+  if (c->run_ref_rows) {  // rows kept as text (few): through the host
+    size_t n = 0;
+    if ((rc = mk_export_exotic(c, nullptr, nullptr, 0, &n)) != MK_OK) return rc;
+    std::vector<uint8_t> km(n * (size_t)c->k + 1), km2;
+    std::vector<uint64_t> cn(n + 1), cn2;
+    if ((rc = mk_export_exotic(c, km.data(), cn.data(), n, &n)) != MK_OK) return rc;
+    for (size_t i = 0; i < n; ++i)
+      if (cn[i] >= min_count) {
+        km2.insert(km2.end(), km.begin() + i * (size_t)c->k, km.begin() + (i + 1) * (size_t)c->k);
+        cn2.push_back(cn[i]);
+      }
+    if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->run_ref.p, c->run_ref_slots)) != MK_OK) return rc;
+    c->run_ref_rows = 0;
+    if (!cn2.empty() && (rc = mk_import_exotic(c, km2.data(), cn2.data(), cn2.size())) != MK_OK) return rc;
+  }
+  MK_HIP(hipStreamSynchronize(c->stream));
+  return MK_OK;
+}
+
 extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
   if (!dst || !src || dst == src) return MK_ERR_ARG;
   mk_ctx* c = dst;
@@ -954,11 +1081,11 @@ extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
   if (dst->in_chunk || src->in_chunk) { c->err = "mk_merge_from: a chunk is open"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(dst->device));
   int rc;
-  if (src->mode == MK_MODE_DENSE || src->mode == MK_MODE_HASH64) {
+  if (src->mode == MK_MODE_DENSE || src->mode == MK_MODE_HASH64 || src->mode == MK_MODE_HASH128) {
     size_t cap = 0;
     if ((rc = mk_export_size(src, &cap)) != MK_OK) { dst->err = src->err; return rc; }
     cap += 1;
-    if ((rc = mk_buf_reserve(dst, dst->surv_keys, cap * 8 + 64)) != MK_OK) return rc;
+    if ((rc = mk_buf_reserve(dst, dst->surv_keys, cap * 8 * (size_t)mk_words_per_key(src) + 64)) != MK_OK) return rc;
     if ((rc = mk_buf_reserve(dst, dst->surv_cnts, cap * 8 + 64)) != MK_OK) return rc;
     size_t rows = 0;
     if ((rc = mk_export_pairs_device(src, (uint64_t*)dst->surv_keys.p, (uint64_t*)dst->surv_cnts.p, cap, &rows)) != MK_OK) {
@@ -993,7 +1120,7 @@ extern "C" int mk_get_stats(mk_ctx* c, mk_stats_t* out) {
   (void)hipSetDevice(c->device);
   prof_collect(c);
   c->st.mode = c->mode;
-  if (c->mode != MK_MODE_DENSE) c->st.rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows;
+  if (c->mode != MK_MODE_DENSE) c->st.rows = c->run_rows + (c->run_side ? 1 : 0) + c->run_ref_rows + c->run128_rows;
   *out = c->st;
   return MK_OK;
 }

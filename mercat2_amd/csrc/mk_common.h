@@ -30,8 +30,12 @@ struct __attribute__((aligned(16))) MkSlot {
   unsigned long long cnt;
 };
 
+// Running table of two-word keys (nucleotide 33..64-mers: hi = bases 0..31, lo = the rest, left-aligned).
+// There is no 128-bit compare-and-swap, so the COUNT word is the slot's state: 0 = free,
+// MK_LOCK128 = claimed, key words being written, anything else = the count (key words final).
+#define MK_LOCK128 0xFFFFFFFFFFFFFFFFull
 struct __attribute__((aligned(32))) MkSlot128 {
-  unsigned long long hi;  // MK_EMPTY = free, MK_EMPTY-1 = being written
+  unsigned long long hi;
   unsigned long long lo;
   unsigned long long cnt;
   unsigned long long pad;
@@ -127,6 +131,9 @@ struct mk_ctx {
   size_t run_ref_rows = 0;
   MkDevBuf arena;       // k bytes per by-reference row
   size_t arena_rows_cap = 0;
+  MkDevBuf run128;      // MkSlot128[]: packed two-word keys (mode MK_MODE_HASH128), u64 counts
+  size_t run128_slots = 0;
+  size_t run128_rows = 0;
 
   // partitioned counting (hash64): keys bucketed by hash, counted per bucket in LDS
   MkDevBuf part;        // u64 keys, bucket after bucket
@@ -146,6 +153,7 @@ struct mk_ctx {
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
+  MkDevBuf ex128, ex128_out;  // two-word rows: compacted {hi, lo, count} + sort scratch; sorted rows for the host
 
   // pinned block ring of mk_count_file (mk_ingest.hip), kept between files
   void* ingest_ring = nullptr;
@@ -207,6 +215,19 @@ int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
                              const uint64_t* nsurv, size_t p1);
 int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows);
+// two-word keys (mk_table.hip): survivors {hi, lo, count} per bucket region / rows {hi, lo} interleaved -> run128
+int mk_launch_import128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, const uint64_t* kstart,
+                                const uint64_t* nsurv, size_t p1);
+int mk_launch_import128_pairs(mk_ctx* c, const uint64_t* d_keys2, const uint64_t* d_counts, size_t rows);
+int mk_launch_refilter64(mk_ctx* c, const MkSlot* from, MkSlot* to, size_t slots, uint64_t min_count, uint64_t* d_kept);
+int mk_launch_refilter128(mk_ctx* c, const MkSlot128* from, MkSlot128* to, size_t slots, uint64_t min_count, uint64_t* d_kept);
+int mk_launch_refilter_dense(mk_ctx* c, uint64_t* bins, size_t nbins, uint64_t min_count);
+int mk_launch_rehash128(mk_ctx* c, const MkSlot128* from, size_t from_slots, MkSlot128* to, size_t to_slots);
+int mk_launch_compact128(mk_ctx* c, const MkSlot128* t, size_t slots, uint64_t* hi, uint64_t* lo, uint64_t* cnts, size_t cap,
+                         uint64_t* d_cursor);
+// mk_sort.hip: rows {hi[i], lo[i], cnt[i]} -> sorted by (hi, lo): keys2_out = {hi, lo} interleaved, cnts_out; scratch = 4 * n words
+int mk_sort_pairs128(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, size_t n, int lo_bits,
+                     uint64_t* scratch, uint64_t* keys2_out, uint64_t* cnts_out);
 // export helpers
 int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys, uint64_t* d_counts, size_t cap,
                       uint64_t* d_cursor);

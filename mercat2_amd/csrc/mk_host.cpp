@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <string.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <utility>
 #include <vector>
 #include "../../include/mercat_hip.h"
 #include "mk_cutscan.h"
@@ -227,3 +229,164 @@ extern "C" int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_
   }
   return MK_OK;
 }
+
+// ------------------------------------------------------------------------------ removeN
+// Restates removeN / split_sequenceN (lib/mercat2_fasta.py:53-119, 21-49): the text rewrite MerCat2 runs on
+// every nucleotide FASTA before counting (bin/mercat2.py:239-244, 276).  Reference behaviour kept:
+//  * text-mode lines (universal newlines), each line str.strip()ped; a header is a stripped line that starts
+//    with '>'; lines in front of the first header are dropped;
+//  * a record whose concatenated sequence holds an upper-case 'N' is cut at every run of N: piece i (from 1,
+//    empty pieces included) gets the header ">{first word}_{i} {other words joined by one blank}" and its
+//    sequence re-wrapped at 80 columns (textwrap.wrap of a string without blanks or hyphens);
+//  * any other record is written as ">" + header text and its stripped lines one by one (empty lines too);
+//  * -toupper upper-cases the sequence lines on output only (a lower-case 'n' is not a cut);
+//  * GC content counts 'G' + 'C' and the length over the concatenated sequence of an unsplit record, and over
+//    EVERY emitted line of a split one, header lines included, before upper-casing (lib/mercat2_fasta.py:99-100).
+// What it does not restate: textwrap's handling of blanks and hyphens INSIDE a sequence that is being split
+// (st->unsupported_record is set and nothing is produced; the Python host layer handles such a file).
+namespace {
+inline bool py_space(unsigned c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+
+struct LineReader {  // text-mode readline + strip over a byte buffer
+  const uint8_t* p;
+  size_t n, pos = 0;
+  LineReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+  // false at EOF; [a, b) = the stripped line
+  bool next(size_t& a, size_t& b) {
+    if (pos >= n) return false;
+    const uint8_t* s = p + pos;
+    const size_t left = n - pos;
+    const uint8_t* nl = (const uint8_t*)memchr(s, '\n', left);
+    size_t len = nl ? (size_t)(nl - s) : left;
+    const uint8_t* cr = (const uint8_t*)memchr(s, '\r', len);
+    size_t term = nl ? 1 : 0;
+    if (cr) {
+      len = (size_t)(cr - s);
+      term = (pos + len + 1 < n && s[len + 1] == '\n') ? 2 : 1;
+    }
+    a = pos;
+    b = pos + len;
+    pos += len + term;
+    while (a < b && py_space(p[a])) ++a;
+    while (b > a && py_space(p[b - 1])) --b;
+    return true;
+  }
+};
+}  // namespace
+
+extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t** out, size_t* out_len, mk_clean_stats_t* st) {
+  if (!out || !out_len || !st || (n && !text)) return MK_ERR_ARG;
+  *out = nullptr;
+  *out_len = 0;
+  memset(st, 0, sizeof *st);
+  st->unsupported_record = -1;
+  for (size_t i = 0; i < n; ++i)
+    if (text[i] >= 0x80) {  // the reference works on decoded characters (lengths, wrapping): left to the Python layer
+      st->unsupported_record = 0;
+      return MK_OK;
+    }
+  std::vector<uint8_t> o;
+  o.reserve(n + n / 64 + 4096);
+  std::vector<uint8_t> seq;
+  std::vector<std::pair<size_t, size_t>> lines;
+  LineReader rd(text, n);
+  size_t a = 0, b = 0;
+  bool have = rd.next(a, b);
+  auto put_seq = [&](const uint8_t* s, size_t len) {
+    const size_t at = o.size();
+    o.insert(o.end(), s, s + len);
+    if (toupper)
+      for (size_t i = at; i < o.size(); ++i)
+        if (o[i] >= 'a' && o[i] <= 'z') o[i] = (uint8_t)(o[i] - 32);
+    o.push_back('\n');
+  };
+  auto count_gc = [&](const uint8_t* s, size_t len) {
+    uint64_t g = 0;
+    for (size_t i = 0; i < len; ++i) g += (s[i] == 'G') | (s[i] == 'C');
+    st->gc_count += g;
+    st->total_length += len;
+  };
+  while (have) {
+    if (!(a < b && text[a] == '>')) {  // not a header: skipped (only happens in front of the first one)
+      have = rd.next(a, b);
+      continue;
+    }
+    const size_t name_a = a + 1, name_b = b;
+    st->records += 1;
+    seq.clear();
+    lines.clear();
+    bool has_n = false;
+    while ((have = rd.next(a, b))) {
+      if (a < b && text[a] == '>') break;
+      lines.emplace_back(a, b);
+      if (!has_n && a < b && memchr(text + a, 'N', b - a)) has_n = true;
+    }
+    if (!has_n) {
+      o.push_back('>');
+      o.insert(o.end(), text + name_a, text + name_b);
+      o.push_back('\n');
+      for (auto& ln : lines) {
+        put_seq(text + ln.first, ln.second - ln.first);
+        count_gc(text + ln.first, ln.second - ln.first);
+      }
+      continue;
+    }
+    // split at runs of N
+    for (auto& ln : lines) seq.insert(seq.end(), text + ln.first, text + ln.second);
+    for (uint8_t ch : seq)
+      if (ch == ' ' || ch == '\t' || ch == 0x0b || ch == 0x0c || ch == '-' || (ch >= 0x1c && ch <= 0x1f)) {
+        st->unsupported_record = (int64_t)st->records - 1;
+        return MK_OK;
+      }
+    // header words
+    std::vector<std::pair<size_t, size_t>> words;
+    for (size_t i = name_a; i < name_b;) {
+      while (i < name_b && py_space(text[i])) ++i;
+      size_t j = i;
+      while (j < name_b && !py_space(text[j])) ++j;
+      if (j > i) words.emplace_back(i, j);
+      i = j;
+    }
+    if (words.empty()) return MK_ERR_RANGE;  // the reference raises IndexError (header.split()[0])
+    st->split_records += 1;
+    size_t i = 0, piece = 0;
+    const size_t L = seq.size();
+    for (;;) {  // pieces = seq.split at N+ (leading / trailing runs give empty pieces)
+      size_t j = i;
+      while (j < L && seq[j] != 'N') ++j;
+      ++piece;
+      const size_t h0 = o.size();
+      o.push_back('>');
+      o.insert(o.end(), text + words[0].first, text + words[0].second);
+      o.push_back('_');
+      char num[24];
+      const int nd = snprintf(num, sizeof num, "%zu", piece);
+      o.insert(o.end(), num, num + nd);
+      o.push_back(' ');
+      for (size_t w = 1; w < words.size(); ++w) {
+        if (w > 1) o.push_back(' ');
+        o.insert(o.end(), text + words[w].first, text + words[w].second);
+      }
+      count_gc(o.data() + h0, o.size() - h0);  // (the reference counts the header line of a split record too)
+      o.push_back('\n');
+      for (size_t q = i; q < j; q += 80) {
+        const size_t len = j - q < 80 ? j - q : 80;
+        count_gc(seq.data() + q, len);
+        put_seq(seq.data() + q, len);
+      }
+      st->pieces += 1;
+      if (j >= L) break;
+      while (j < L && seq[j] == 'N') ++j;  // the run
+      st->n_runs += 1;
+      i = j;
+    }
+  }
+  uint8_t* mem = (uint8_t*)malloc(o.size() ? o.size() : 1);
+  if (!mem) return MK_ERR_NOMEM;
+  memcpy(mem, o.data(), o.size());
+  *out = mem;
+  *out_len = o.size();
+  return MK_OK;
+}
+
+extern "C" void mk_free(void* p) { free(p); }

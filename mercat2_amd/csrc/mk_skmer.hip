@@ -420,24 +420,27 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------ 4 count
-// Stage layout: entry g lives at skc_swz(g). Lane l writes entries ~8l+i (prefix sums of the record
-// lengths), i.e. a 64-byte lane stride that would put 32 lanes on 2 of the 16 eight-byte bank
-// pairs; rotating each 16-entry block by its block number spreads them over all 16 (2-way).
-__device__ __forceinline__ unsigned skc_swz(unsigned g) { return (g & ~15u) | ((g + (g >> 4)) & 15u); }
+// What the insert costs (measured, tools/lds_probe.hip and the ISA of the round-1 kernel): the kernel is
+// bound by VALU issue, not by the LDS.  One compare-and-swap plus one add per key take ~30 clocks of the
+// CU's LDS per 64 keys; the round-1 kernel spent ~150.  Where it went: (a) every key that did not find its
+// home slot took a serial probe loop, inlined and unrolled 16 x 48 times (110 KB of code, 1072 spilled
+// SGPRs), and nearly every wave has a few such keys in every slot of its batch, so the whole wave walked
+// eight probe loops with a handful of active lanes; (b) three quarter-rate 32-bit multiplies per key.
+// Now: (a) a key whose home slot holds another key is DEFERRED: it goes onto a per-wave stack in LDS (slot
+// positions from ballots, no atomic) and the wave probes 64 deferred keys at a time, every lane busy;
+// (b) the slot hash is three full-rate 24-bit multiplies.
 
-// 32-bit hash of a packed key for the LDS table: bits 31..19 pick the slot, bits 15..0 the
-// sub-range (3 multiplies instead of the 8 of mk_mix64; only balance matters here).
+// 32-bit hash of a packed key for the LDS table: bits 31..19 pick the slot, bits 15..0 the sub-range.
+// Three 24-bit multiplies (v_mul_u32_u24 issues at full rate; a 32-bit multiply at a quarter) over the three
+// 24-bit pieces of the key; as even as a random function on the keys of a bucket (windows of the same loci,
+// shifted by one base: tools/hash_quality.py).
 __device__ __forceinline__ unsigned skc_hash(u64 key) {
-  unsigned h = (unsigned)key * 0x9E3779B1u ^ (unsigned)(key >> 32) * 0x85EBCA77u;
-  h ^= h >> 15;
-  h *= 0xC2B2AE3Du;
-  h ^= h >> 16;
-  return h;
+  const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+  const unsigned mid = __funnelshift_r(lo, hi, 24);  // bits 24..55 (the multiply takes its low 24)
+  return __umul24(lo, 0x9E3779u) ^ __umul24(mid, 0x85EBCBu) ^ __umul24(hi >> 16, 0xC2B2AFu);
 }
 
 #define SKC_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
-// Linear probing from slot home+SKC_STEPS on (the caller has seen the first SKC_STEPS slots taken by other keys).
-#define SKC_STEPS 1  // batched probe steps before the serial loop
 // home slot of a hash and the slot d steps further (any table size; a power of two costs a shift and a mask)
 __device__ __forceinline__ unsigned skc_home(unsigned h) {
   if constexpr ((SKC_SLOTS & (SKC_SLOTS - 1)) == 0) return h >> (32 - __builtin_ctz(SKC_SLOTS));
@@ -448,22 +451,42 @@ __device__ __forceinline__ unsigned skc_step(unsigned slot, unsigned d) {
   if constexpr ((SKC_SLOTS & (SKC_SLOTS - 1)) == 0) return slot & (SKC_SLOTS - 1);
   else return slot >= SKC_SLOTS ? slot - SKC_SLOTS : slot;
 }
-__device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned h) {
-  unsigned slot = skc_step(skc_home(h), SKC_STEPS);
-  u64 cur = tkey[slot];
-  for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
-    if (cur == MK_EMPTY) {
-      cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
-      if (cur == MK_EMPTY) cur = key;
-    }
-    if (cur == key) { atomicAdd(&tcnt[slot], 1u); return; }
-    slot = skc_step(slot, 1);
-    cur = tkey[slot];
-  }
-  atomicOr(s_overflow, 1u);  // (a plain volatile LDS store here trips a gfx950 backend assertion in ROCm 7.2)
+
+#define SKC_B 8          // k-mers of a record expanded and probed together
+#define SKC_WAVES (SKC_THREADS / 64)
+#define SKC_QCAP 320     // deferred keys a wave can hold: < 64 left over + 4 slots x 64 lanes pushed at once
+
+__device__ __forceinline__ unsigned skc_lane_rank(u64 mask) {  // set bits of mask below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
 
-#define SKC_B 8  // k-mers of a record expanded and probed together
+// The top n (<= 64) deferred keys of this wave's stack: linear probing from the slot after the home slot
+// (the home slot is known to hold another key), one key per lane.
+__device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* q, unsigned& qcount, unsigned n,
+                                          unsigned* s_overflow) {
+  const unsigned lane = threadIdx.x & 63;
+  qcount -= n;
+  if (lane < n) {
+    const u64 key = q[qcount + lane];
+    unsigned slot = skc_step(skc_home(skc_hash(key)), 1);
+    bool placed = false;
+#pragma unroll 1
+    for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
+      u64 cur = tkey[slot];
+      if (cur == MK_EMPTY) {
+        cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
+        if (cur == MK_EMPTY) cur = key;
+      }
+      if (cur == key) {
+        atomicAdd(&tcnt[slot], 1u);
+        placed = true;
+        break;
+      }
+      slot = skc_step(slot, 1);
+    }
+    if (!placed) atomicOr(s_overflow, 1u);  // (a plain volatile LDS store here trips a gfx950 backend assertion in ROCm 7.2)
+  }
+}
 
 #ifdef MK_STAMP
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
@@ -476,18 +499,18 @@ __device__ __forceinline__ void skc_probe(u64* tkey, unsigned* tcnt, unsigned* s
 // Persistent: gridDim.x workgroups (one per CU) walk the buckets b = blockIdx.x, +gridDim.x, ...
 // The next bucket's bounds and its first two record batches are loaded while the current
 // bucket is being emitted, so no global-memory latency sits on the critical path.
-#ifdef SKC_WAVES_PER_EU
-__attribute__((amdgpu_waves_per_eu(SKC_WAVES_PER_EU, SKC_WAVES_PER_EU)))
-#endif
+// K32: k == 32, the only k whose keys can equal the free-slot mark (32 x 'T'): that key is counted aside.
+template <bool CANON, bool K32>
 __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
                                                              const u64* __restrict__ cursor,
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
                                                              int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
-                                                             int dflags, int canon) {
+                                                             int dflags) {
   __shared__ __attribute__((aligned(16))) u64 tkey[SKC_SLOTS];
   __shared__ __attribute__((aligned(16))) unsigned tcnt[SKC_SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 wq[SKC_WAVES][SKC_QCAP];  // deferred keys, one stack per wave
   // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
@@ -502,6 +525,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   unsigned par = 0;
   const int kshift = 64 - 2 * k;
   const int lane = threadIdx.x & 63;
+  u64* const myq = wq[threadIdx.x >> 6];
   u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
   u64 windows = 0, records_total = 0;  // what the chunk held (every record is expanded at least once)
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, npass = 0;
@@ -568,6 +592,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         win_pass = 0;
         bool over = false;
         unsigned* const ovf = &s_overflow[par];
+        unsigned qcount = 0;  // this wave's deferred keys (wave-uniform)
         for (u64 rb2 = 0; rb2 < n && !over; rb2 += SKC_PRE * SKC_THREADS) {
           ulonglong2 recs2[SKC_PRE];
           if (first_pass && rb2 == 0) {
@@ -583,65 +608,69 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           STAMP_ADD(tF, t0);
 #pragma unroll
           for (int h = 0; h < SKC_PRE; ++h) {
-            // ---- one record per thread, expanded 8 k-mers at a time; the 8 first probes are
-            //      issued together, the (rare) collisions and new keys take the slow path
+            // ---- one record per thread, expanded 8 k-mers at a time: the 8 compare-and-swaps on the home
+            //      slots are issued together, then the adds of the keys that found (or claimed) their slot;
+            //      the others are deferred
             const ulonglong2 rec = recs2[h];
             const int nk = (int)(rec.y & 63);
             win_pass += side_done ? 0 : (u64)nk;
             u64 x = rec.x, y = rec.y;
-            for (int base = 0; base < nk; base += SKC_B) {
+            // (the whole wave walks the loop together -- lanes without a record or with a short one just have
+            // no live slots -- because the deferred-key stack below is the wave's: every lane takes part)
+            for (int base = 0; __any(base < nk); base += SKC_B) {
               u64 kk[SKC_B], cur[SKC_B];
               unsigned hh[SKC_B];
+              unsigned live = 0;  // bit u: slot u holds a key of this pass
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u) {
-                kk[u] = (base + u < nk) ? mk_canon2(x >> kshift, k, canon != 0) : MK_EMPTY;
-                if (base + u < nk && kk[u] == MK_EMPTY) side_pass += side_done ? 0 : 1;
+                kk[u] = mk_canon2(x >> kshift, k, CANON);
                 x = (x << 2) | (y >> 62);
                 y <<= 2;
-              }
-#pragma unroll
-              for (int u = 0; u < SKC_B; ++u) {
                 hh[u] = skc_hash(kk[u]);
-                if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) kk[u] = MK_EMPTY;
+                bool on = base + u < nk;
+                if (K32 && on && kk[u] == MK_EMPTY) {
+                  side_pass += side_done ? 0 : 1;
+                  on = false;
+                }
+                live |= on ? (1u << u) : 0u;
               }
-              // up to SKC_STEPS probe steps with the whole batch in flight: reads of slot home+step,
-              // then the compare-and-swaps of the empty ones, then the adds. A key is done once its
-              // slot holds it; what is still unresolved after the last step (a few %) probes serially.
-#pragma unroll
-              for (int step = 0; step < SKC_STEPS; ++step) {
-#if SKC_CAS_FIRST
+              if (s) {
 #pragma unroll
                 for (int u = 0; u < SKC_B; ++u)
-                  if (kk[u] != MK_EMPTY) {
-                    cur[u] = atomicCAS(&tkey[skc_step(skc_home(hh[u]), step)], MK_EMPTY, kk[u]);
-                    if (cur[u] == MK_EMPTY) cur[u] = kk[u];
-                  }
-#else
-#pragma unroll
-                for (int u = 0; u < SKC_B; ++u)
-                  if (kk[u] != MK_EMPTY) cur[u] = tkey[skc_step(skc_home(hh[u]), step)];
-#pragma unroll
-                for (int u = 0; u < SKC_B; ++u)
-                  if (kk[u] != MK_EMPTY && cur[u] == MK_EMPTY) {
-                    cur[u] = atomicCAS(&tkey[skc_step(skc_home(hh[u]), step)], MK_EMPTY, kk[u]);
-                    if (cur[u] == MK_EMPTY) cur[u] = kk[u];
-                  }
-#endif
-#pragma unroll
-                for (int u = 0; u < SKC_B; ++u)
-                  if (kk[u] != MK_EMPTY && cur[u] == kk[u]) {
-                    atomicAdd(&tcnt[skc_step(skc_home(hh[u]), step)], 1u);
-                    kk[u] = MK_EMPTY;  // resolved
-                  }
+                  if (((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) live &= ~(1u << u);
               }
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u)
-                if (kk[u] != MK_EMPTY) skc_probe(tkey, tcnt, ovf, kk[u], hh[u]);
+                if ((live >> u) & 1u) cur[u] = atomicCAS(&tkey[skc_home(hh[u])], MK_EMPTY, kk[u]);
+              unsigned fail = 0;
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u)
+                if ((live >> u) & 1u) {
+                  if (cur[u] == MK_EMPTY || cur[u] == kk[u]) atomicAdd(&tcnt[skc_home(hh[u])], 1u);
+                  else fail |= 1u << u;
+                }
+              // deferred keys -> the wave's stack (positions from ballots: no atomic), four slots at a time
+              // so that the stack never holds more than SKC_QCAP; full groups of 64 are probed right away
+#pragma unroll
+              for (int half = 0; half < SKC_B; half += 4) {
+#pragma unroll
+                for (int u = half; u < half + 4; ++u) {
+                  const bool f = (fail >> u) & 1u;
+                  const u64 m = __ballot(f);
+                  if (m) {
+                    if (f) myq[qcount + skc_lane_rank(m)] = kk[u];
+                    qcount += (unsigned)__popcll(m);
+                  }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                while (qcount >= 64) skc_drain(tkey, tcnt, myq, qcount, 64u, ovf);
+              }
             }
           }
           STAMP_ADD(tC, t0);
           if (*(volatile unsigned*)ovf) over = true;  // hint only; decided after the barrier below
         }
+        if (qcount) skc_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
         first_pass = false;
         __syncthreads();  // A: every insert of the pass is in the table
         STAMP_ADD(tF, t0);
@@ -761,7 +790,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
     if (dbg) { u64* d = dbg + (size_t)blockIdx.x * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = tF; d[6] = npass; }
 #endif
   }
-  wave_add(&info->side, side);
+  if (K32) wave_add(&info->side, side);
 }
 
 // ------------------------------------------------------------------------------ launcher
@@ -874,10 +903,14 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     if (!mk_dbg_ptr) (void)hipMalloc((void**)&mk_dbg_ptr, 8 * 8 * 1024);
     dbgbuf = mk_dbg_ptr;
 #endif
-    hipLaunchKernelGGL(mk_sk_count_k, dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p,
-                       (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                       (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf,
-                       getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0, c->canonical);
+    const int dflags = getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0;
+#define SKC_LAUNCH(CANON, K32)                                                                                          \
+  hipLaunchKernelGGL((mk_sk_count_k<CANON, K32>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
+                     (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count,            \
+                     (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf, dflags)
+    if (c->canonical) { if (k == 32) SKC_LAUNCH(true, true); else SKC_LAUNCH(true, false); }
+    else { if (k == 32) SKC_LAUNCH(false, true); else SKC_LAUNCH(false, false); }
+#undef SKC_LAUNCH
   }
   mk_prof_end(c);
 #ifdef MK_STAMP

@@ -113,3 +113,58 @@ int mk_launch_rows_gather(mk_ctx* c, const uint8_t* arena, const uint64_t* order
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
+
+// ------------------------------------------------------------------ two-word packed rows
+// Rows {hi, lo, count} of the 33..64-mer table in key order (hi, then lo == byte order of the k-mer text):
+// least-significant word first -- a stable sort of the row numbers by lo (only its used bits), then by hi --
+// and one gather that writes the rows {hi, lo} interleaved.  scratch: 4 * n words.
+__global__ void mk_iota_k(unsigned long long* __restrict__ v, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) v[i] = i;
+}
+__global__ void mk_gather_u64_k(const unsigned long long* __restrict__ src, const unsigned long long* __restrict__ idx, size_t n,
+                                unsigned long long* __restrict__ dst) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+__global__ void mk_gather_rows128_k(const unsigned long long* __restrict__ hi, const unsigned long long* __restrict__ lo,
+                                    const unsigned long long* __restrict__ cnt, const unsigned long long* __restrict__ idx, size_t n,
+                                    ulonglong2* __restrict__ keys2, unsigned long long* __restrict__ cnts) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long r = idx[i];
+    keys2[i] = make_ulonglong2(hi[r], lo[r]);
+    cnts[i] = cnt[r];
+  }
+}
+
+static int sort_pairs_bits(mk_ctx* c, const uint64_t* keys_in, const uint64_t* vals_in, uint64_t* keys_out, uint64_t* vals_out,
+                           size_t n, unsigned begin_bit, unsigned end_bit) {
+  size_t tmp_bytes = 0;
+  MK_HIP(rocprim::radix_sort_pairs((void*)nullptr, tmp_bytes, (const unsigned long long*)keys_in, (unsigned long long*)keys_out,
+                                   (const unsigned long long*)vals_in, (unsigned long long*)vals_out, n, begin_bit, end_bit, c->stream));
+  int rc = mk_buf_reserve(c, c->ex_tmp, tmp_bytes ? tmp_bytes : 16);
+  if (rc) return rc;
+  MK_HIP(rocprim::radix_sort_pairs(c->ex_tmp.p, tmp_bytes, (const unsigned long long*)keys_in, (unsigned long long*)keys_out,
+                                   (const unsigned long long*)vals_in, (unsigned long long*)vals_out, n, begin_bit, end_bit, c->stream));
+  return MK_OK;
+}
+
+int mk_sort_pairs128(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, size_t n, int lo_bits,
+                     uint64_t* scratch, uint64_t* keys2_out, uint64_t* cnts_out) {
+  if (n == 0) return MK_OK;
+  int rc;
+  unsigned long long* idx_a = (unsigned long long*)scratch;
+  unsigned long long* idx_b = idx_a + n;
+  unsigned long long* key_a = idx_b + n;
+  unsigned long long* key_b = key_a + n;
+  const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(mk_iota_k, dim3(grid), dim3(256), 0, c->stream, idx_a, n);
+  // (all 64 bits of lo: its unused low bits are zero.  A sub-range [64 - lo_bits, 64) left rows with equal
+  // hi out of lo order on gfx950 / rocPRIM 7.2 at a few 100 k rows -- measured, tools/dbg128.py)
+  (void)lo_bits;
+  if ((rc = sort_pairs_bits(c, lo, (const uint64_t*)idx_a, (uint64_t*)key_a, (uint64_t*)idx_b, n, 0u, 64u)) != MK_OK) return rc;
+  hipLaunchKernelGGL(mk_gather_u64_k, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long*)hi, (const unsigned long long*)idx_b, n, key_a);
+  if ((rc = sort_pairs_bits(c, (const uint64_t*)key_a, (const uint64_t*)idx_b, (uint64_t*)key_b, (uint64_t*)idx_a, n, 0u, 64u)) != MK_OK) return rc;
+  hipLaunchKernelGGL(mk_gather_rows128_k, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long*)hi, (const unsigned long long*)lo,
+                     (const unsigned long long*)cnts, (const unsigned long long*)idx_a, n, (ulonglong2*)keys2_out, (unsigned long long*)cnts_out);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}

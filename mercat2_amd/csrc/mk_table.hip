@@ -128,6 +128,139 @@ __global__ void mk_import_bins_k(const u64* __restrict__ keys, const u64* __rest
     if (keys[i] < nbins) atomicAdd(&bins[keys[i]], cnts[i]);
 }
 
+// ------------------------------------------------------------- running table: two-word keys
+// Insert-add of one {hi, lo} key (protocol: MkSlot128 in mk_common.h).  A lane that claims a slot writes the
+// key words and publishes the count inside the loop iteration in which it won, so lanes of the same wave that
+// meet MK_LOCK128 and look again cannot starve it.  Returns true when the key was new.
+__device__ __forceinline__ u64 home128(u64 hi, u64 lo, u64 mask) { return mk_mix64(hi ^ mk_mix64(lo + MK_POLY_B)) & mask; }
+
+__device__ __forceinline__ bool upsert128(MkSlot128* __restrict__ t, u64 mask, u64 hi, u64 lo, u64 add) {
+  u64 slot = home128(hi, lo, mask);
+  bool done = false, fresh = false;
+  while (!done) {
+    u64 st = __hip_atomic_load(&t[slot].cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (st == 0) {
+      st = atomicCAS(&t[slot].cnt, 0ull, MK_LOCK128);
+      if (st == 0) {
+        __hip_atomic_store(&t[slot].hi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&t[slot].lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&t[slot].cnt, add, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        done = true;
+        fresh = true;
+      }
+    }
+    if (!done && st != MK_LOCK128) {  // a published slot: its key words are final
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      const u64 h2 = __hip_atomic_load(&t[slot].hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 l2 = __hip_atomic_load(&t[slot].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (h2 == hi && l2 == lo) {
+        atomicAdd(&t[slot].cnt, add);
+        done = true;
+      } else {
+        slot = (slot + 1) & mask;
+      }
+    }
+  }
+  return fresh;
+}
+
+// Survivors of the partitioned 33..64-mer path: {hi, lo, count} per bucket region. One wave per bucket.
+__global__ void mk_import128_regions_k(const u64* __restrict__ hi, const u64* __restrict__ lo, const u64* __restrict__ cnts,
+                                       const u64* __restrict__ kstart, const u64* __restrict__ nsurv, size_t p1,
+                                       MkSlot128* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  const int lane = threadIdx.x & 63;
+  for (size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < p1; b += (size_t)gridDim.x * (blockDim.x >> 6)) {
+    const u64 base = kstart[b], n = nsurv[b];
+    for (u64 i = lane; i < n; i += 64) fresh += upsert128(run, run_mask, hi[base + i], lo[base + i], cnts[base + i]) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+
+int mk_launch_import128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, const uint64_t* kstart,
+                                const uint64_t* nsurv, size_t p1) {
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_import128_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream, (const u64*)hi,
+                     (const u64*)lo, (const u64*)cnts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot128*)c->run128.p,
+                     (u64)(c->run128_slots - 1), &info->new_rows);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// Rows {hi, lo} interleaved + counts (another context's or rank's table; the same key may come more than once).
+__global__ void mk_import128_pairs_k(const u64* __restrict__ keys2, const u64* __restrict__ cnts, size_t rows,
+                                     MkSlot128* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x)
+    if (cnts[i]) fresh += upsert128(run, run_mask, keys2[2 * i], keys2[2 * i + 1], cnts[i]) ? 1 : 0;
+  block_add(new_rows, fresh);
+}
+
+int mk_launch_import128_pairs(mk_ctx* c, const uint64_t* d_keys2, const uint64_t* d_counts, size_t rows) {
+  if (!rows) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_import128_pairs_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys2,
+                     (const u64*)d_counts, rows, (MkSlot128*)c->run128.p, (u64)(c->run128_slots - 1), &info->new_rows);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// Re-insert after growth: rows are distinct and final -> claim the first free slot.
+__global__ void mk_rehash128_k(const MkSlot128* __restrict__ from, size_t slots, MkSlot128* __restrict__ to, u64 to_mask) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong4 s = reinterpret_cast<const ulonglong4*>(from)[i];
+    if (s.z == 0) continue;
+    u64 slot = home128(s.x, s.y, to_mask);
+    for (;;) {
+      if (atomicCAS(&to[slot].cnt, 0ull, s.z) == 0ull) {
+        to[slot].hi = s.x;
+        to[slot].lo = s.y;
+        break;
+      }
+      slot = (slot + 1) & to_mask;
+    }
+  }
+}
+
+int mk_launch_rehash128(mk_ctx* c, const MkSlot128* from, size_t from_slots, MkSlot128* to, size_t to_slots) {
+  if (!from_slots) return MK_OK;
+  hipLaunchKernelGGL(mk_rehash128_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots, to,
+                     (u64)(to_slots - 1));
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
+// Occupied slots -> {hi, lo, count} in arbitrary order; *cursor counts them (wave-aggregated cursor).
+__global__ __launch_bounds__(256) void mk_compact128_k(const MkSlot128* __restrict__ t, size_t slots, u64* __restrict__ hi,
+                                                       u64* __restrict__ lo, u64* __restrict__ cnts, size_t cap,
+                                                       u64* __restrict__ cursor) {
+  const int lane = threadIdx.x & 63;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const size_t rounds = (slots + stride - 1) / stride;
+  for (size_t r = 0; r < rounds; ++r) {
+    const size_t i = r * stride + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ulonglong4 s = make_ulonglong4(0, 0, 0, 0);
+    if (i < slots) s = reinterpret_cast<const ulonglong4*>(t)[i];
+    const bool keep = s.z != 0;
+    const u64 m = __ballot(keep);
+    if (m) {
+      u64 at = 0;
+      if (lane == 0) at = atomicAdd(cursor, (u64)__popcll(m));
+      const u64 pos = __shfl(at, 0) + __popcll(m & ((1ull << lane) - 1));
+      if (keep && pos < cap) { hi[pos] = s.x; lo[pos] = s.y; cnts[pos] = s.z; }
+    }
+  }
+}
+
+int mk_launch_compact128(mk_ctx* c, const MkSlot128* t, size_t slots, uint64_t* hi, uint64_t* lo, uint64_t* cnts, size_t cap,
+                         uint64_t* d_cursor) {
+  if (!slots) return MK_OK;
+  hipLaunchKernelGGL(mk_compact128_k, dim3(grid_for(slots, 256, 4096)), dim3(256), 0, c->stream, t, slots, (u64*)hi, (u64*)lo,
+                     (u64*)cnts, cap, (u64*)d_cursor);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 // ------------------------------------------------------------------- running table: dense
 __global__ void mk_accumulate_dense_k(u64* __restrict__ chunk, size_t nbins, u64 min_count, u64* __restrict__ run) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (size_t)gridDim.x * blockDim.x) {
@@ -210,42 +343,35 @@ __device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, u
   return upsert_ref_of(run, mask, arena, BytesAt{str}, k, add, arena_base, new_rows);
 }
 
-// Survivors of the partitioned 33..64-mer path: {hi, lo, count} per bucket region (kstart/nsurv as
-// for mk_import_regions_k) -> by-reference running table. One wave per bucket.
-__global__ void mk_import_ref128_regions_k(const u64* __restrict__ hi, const u64* __restrict__ lo, const u64* __restrict__ cnts,
-                                           const u64* __restrict__ kstart, const u64* __restrict__ nsurv, size_t p1, int k,
-                                           MkSlot* __restrict__ run, u64 run_mask, uint8_t* __restrict__ arena,
-                                           u64 arena_base, u64* __restrict__ new_rows) {
-  const int lane = threadIdx.x & 63;
-  for (size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < p1; b += (size_t)gridDim.x * (blockDim.x >> 6)) {
-    const u64 base = kstart[b], n = nsurv[b];
-    for (u64 i = lane; i < n; i += 64)
-      upsert_ref_of(run, run_mask, arena, Key128Text{hi[base + i], lo[base + i]}, k, cnts[base + i], arena_base, new_rows);
-  }
-}
-
-int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,
-                                    const uint64_t* kstart, const uint64_t* nsurv, size_t p1) {
-  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
-  hipLaunchKernelGGL(mk_import_ref128_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream,
-                     (const u64*)hi, (const u64*)lo, (const u64*)cnts, (const u64*)kstart, (const u64*)nsurv, p1, c->k,
-                     (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1), (uint8_t*)c->arena.p, (u64)c->run_ref_rows,
-                     &info->new_rows_ref);
-  MK_HIP(hipGetLastError());
-  return MK_OK;
-}
-
 // Survivors of the by-reference chunk table -> running by-reference table. Within one launch
 // every inserted string is distinct (they come from distinct chunk slots), so once a thread
 // has reserved an arena row (my_row) its string is known to be new and it only looks for a
 // free slot.
+// run128 != nullptr (contexts of nucleotide 33..64-mers): a surviving row whose k bytes are all ACGT is a
+// packed two-word key and goes to the packed table (every such key lives there and only there); rows
+// holding other characters stay text.
 __global__ void mk_accumulate_ref_k(const MkSlot* __restrict__ from, size_t slots, u64 min_count,
                                     const uint8_t* __restrict__ seq, int k, MkSlot* __restrict__ run, u64 run_mask,
-                                    uint8_t* __restrict__ arena, u64 arena_base, u64* __restrict__ new_rows) {
+                                    uint8_t* __restrict__ arena, u64 arena_base, u64* __restrict__ new_rows,
+                                    MkSlot128* __restrict__ run128, u64 run128_mask, u64* __restrict__ new_rows128) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
     ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
-    if (s.x != MK_EMPTY && s.y >= min_count && s.y != 0)
-      upsert_ref(run, run_mask, arena, seq + (s.x & REF_POS_MASK), k, s.y, arena_base, new_rows);
+    if (s.x != MK_EMPTY && s.y >= min_count && s.y != 0) {
+      const uint8_t* str = seq + (s.x & REF_POS_MASK);
+      bool packed = run128 != nullptr;
+      u64 hi = 0, lo = 0;
+      if (packed) {
+        for (int j = 0; j < k && packed; ++j) {
+          const unsigned ch = str[j];
+          const unsigned code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+          if (code > 3u) packed = false;
+          else if (j < 32) hi |= (u64)code << (62 - 2 * j);
+          else lo |= (u64)code << (62 - 2 * (j - 32));
+        }
+      }
+      if (packed) { if (upsert128(run128, run128_mask, hi, lo, s.y)) atomicAdd(new_rows128, 1ull); }
+      else upsert_ref(run, run_mask, arena, str, k, s.y, arena_base, new_rows);
+    }
   }
 }
 
@@ -291,6 +417,67 @@ __global__ void mk_rehash64_k(const MkSlot* __restrict__ from, size_t slots, MkS
   }
 }
 
+// Rebuild keeping only rows with count >= min_count (the post-merge filter of a single-chunk sample split
+// over several ranks); *kept counts them.
+__global__ void mk_refilter64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, u64 to_mask, u64 min_count,
+                                u64* __restrict__ kept) {
+  u64 mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
+    if (s.x == MK_EMPTY || s.y < min_count || s.y == 0) continue;
+    ++mine;
+    u64 slot = mk_mix64(s.x) & to_mask;
+    for (;;) {
+      if (atomicCAS(&to[slot].key, MK_EMPTY, s.x) == MK_EMPTY) {
+        to[slot].cnt = s.y;
+        break;
+      }
+      slot = (slot + 1) & to_mask;
+    }
+  }
+  block_add(kept, mine);
+}
+__global__ void mk_refilter128_k(const MkSlot128* __restrict__ from, size_t slots, MkSlot128* __restrict__ to, u64 to_mask,
+                                 u64 min_count, u64* __restrict__ kept) {
+  u64 mine = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong4 s = reinterpret_cast<const ulonglong4*>(from)[i];
+    if (s.z == 0 || s.z < min_count) continue;
+    ++mine;
+    u64 slot = home128(s.x, s.y, to_mask);
+    for (;;) {
+      if (atomicCAS(&to[slot].cnt, 0ull, s.z) == 0ull) {
+        to[slot].hi = s.x;
+        to[slot].lo = s.y;
+        break;
+      }
+      slot = (slot + 1) & to_mask;
+    }
+  }
+  block_add(kept, mine);
+}
+__global__ void mk_refilter_dense_k(u64* __restrict__ bins, size_t nbins, u64 min_count) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbins; i += (size_t)gridDim.x * blockDim.x)
+    if (bins[i] < min_count) bins[i] = 0;
+}
+int mk_launch_refilter64(mk_ctx* c, const MkSlot* from, MkSlot* to, size_t slots, uint64_t min_count, uint64_t* d_kept) {
+  hipLaunchKernelGGL(mk_refilter64_k, dim3(grid_for(slots, 256, 8192)), dim3(256), 0, c->stream, from, slots, to, (u64)(slots - 1),
+                     (u64)min_count, (u64*)d_kept);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+int mk_launch_refilter128(mk_ctx* c, const MkSlot128* from, MkSlot128* to, size_t slots, uint64_t min_count, uint64_t* d_kept) {
+  hipLaunchKernelGGL(mk_refilter128_k, dim3(grid_for(slots, 256, 8192)), dim3(256), 0, c->stream, from, slots, to, (u64)(slots - 1),
+                     (u64)min_count, (u64*)d_kept);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+int mk_launch_refilter_dense(mk_ctx* c, uint64_t* bins, size_t nbins, uint64_t min_count) {
+  hipLaunchKernelGGL(mk_refilter_dense_k, dim3(grid_for(nbins)), dim3(256), 0, c->stream, (u64*)bins, nbins, (u64)min_count);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots) {
   if (!from_slots) return MK_OK;
   hipLaunchKernelGGL(mk_rehash64_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots, to,
@@ -324,7 +511,9 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count) {
     hipLaunchKernelGGL(mk_accumulate_ref_k, dim3(grid_for(c->rtab_chunk_slots, 256, 8192)), dim3(256), 0, c->stream,
                        (const MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots, (u64)min_count, (const uint8_t*)c->seq.p,
                        c->k, (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1), (uint8_t*)c->arena.p,
-                       (u64)c->run_ref_rows, &info->new_rows_ref);
+                       (u64)c->run_ref_rows, &info->new_rows_ref,
+                       c->mode == MK_MODE_HASH128 ? (MkSlot128*)c->run128.p : (MkSlot128*)nullptr,
+                       (u64)(c->run128_slots ? c->run128_slots - 1 : 0), &info->new_rows);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
@@ -458,6 +647,39 @@ __global__ __launch_bounds__(256) void mk_alpha_k(const MkSlot* __restrict__ slo
   if (threadIdx.x < 11 && s_freq[threadIdx.x]) atomicAdd(&out[2 + threadIdx.x], (u64)s_freq[threadIdx.x]);
 }
 
+__global__ __launch_bounds__(256) void mk_alpha128_k(const MkSlot128* __restrict__ slots, size_t nslots, u64* __restrict__ out) {
+  __shared__ unsigned s_freq[11];
+  __shared__ unsigned long long s_rows, s_total;
+  __shared__ double s_sq, s_clnc;
+  if (threadIdx.x < 11) s_freq[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_rows = 0; s_total = 0; s_sq = 0; s_clnc = 0; }
+  __syncthreads();
+  u64 rows = 0, total = 0;
+  double sq = 0, clnc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nslots; i += (size_t)gridDim.x * blockDim.x)
+    alpha_take(slots[i].cnt, rows, total, sq, clnc, s_freq);
+  for (int d = 32; d > 0; d >>= 1) {
+    rows += __shfl_down(rows, d);
+    total += __shfl_down(total, d);
+    sq += __shfl_down(sq, d);
+    clnc += __shfl_down(clnc, d);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&s_rows, (unsigned long long)rows);
+    atomicAdd(&s_total, (unsigned long long)total);
+    atomicAdd(&s_sq, sq);
+    atomicAdd(&s_clnc, clnc);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (s_rows) atomicAdd(&out[0], (u64)s_rows);
+    if (s_total) atomicAdd(&out[1], (u64)s_total);
+    if (s_sq != 0) atomicAdd(reinterpret_cast<double*>(&out[13]), s_sq);
+    if (s_clnc != 0) atomicAdd(reinterpret_cast<double*>(&out[14]), s_clnc);
+  }
+  if (threadIdx.x < 11 && s_freq[threadIdx.x]) atomicAdd(&out[2 + threadIdx.x], (u64)s_freq[threadIdx.x]);
+}
+
 int mk_launch_alpha(mk_ctx* c, u64* d_out) {
   MK_HIP(hipMemsetAsync(d_out, 0, 16 * sizeof(u64), c->stream));
   if (c->mode == MK_MODE_DENSE) {
@@ -470,6 +692,9 @@ int mk_launch_alpha(mk_ctx* c, u64* d_out) {
   if (c->run_ref_slots)
     hipLaunchKernelGGL(mk_alpha_k, dim3(grid_for(c->run_ref_slots, 256, 1024)), dim3(256), 0, c->stream,
                        (const MkSlot*)c->run_ref.p, c->run_ref_slots, (const u64*)nullptr, (size_t)0, d_out);
+  if (c->run128_slots)
+    hipLaunchKernelGGL(mk_alpha128_k, dim3(grid_for(c->run128_slots, 256, 1024)), dim3(256), 0, c->stream,
+                       (const MkSlot128*)c->run128.p, c->run128_slots, d_out);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }

@@ -5,14 +5,19 @@ Replaces the reference's cross-worker merge -- ``ray.get`` of every chunk's dict
 sum in run_mercat2 (bin/mercat2.py:121-127).  Chunks are dealt to ranks round-robin; every rank
 filters its own chunks (the per-chunk min_count rule) and accumulates the survivors into its
 running table.  The only exchange step is this one: rows are re-partitioned by KEY RANGE
-(owner = floor(key * world / 2^bits)), sent with one all_to_all per array straight between
-peers (each pair of GPUs has its own xGMI link, so all 7 links carry traffic at once; no ring),
-and insert-added at the owner.  Each owner then holds a contiguous, sorted key range, so the
-globally sorted table is the concatenation of the ranks' exports in rank order.
+(owner = floor(key * world / 2^bits) of the key's first word), sent with ONE all_to_all straight
+between peers -- key words and count of a row travel side by side; each pair of GPUs has its own
+xGMI link, so all 7 links carry traffic at once; no ring -- and insert-added at the owner.  Each
+owner then holds a contiguous, sorted key range, so the globally sorted table is the concatenation of
+the ranks' exports in rank order.  Two-word keys (33..64-mers) travel the same way as {hi, lo, count}.
+
+A sample that is ONE chunk (file below the -s threshold) has one filter unit: ``count_single_chunk``
+splits its records into one range per rank, counts them unfiltered, merges, and applies min_count at
+the owners after the merge (lib/mercat2_kmers.py:73-76 applied once per file).
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -35,69 +40,119 @@ def split_points(sorted_keys: torch.Tensor, key_bits: int, world: int) -> torch.
     """Index of the first row of every rank's range in an ascending (unsigned) key tensor."""
     b = torch.tensor([x - (1 << 64) if x >= (1 << 63) else x for x in range_bounds(key_bits, world)],
                      dtype=torch.int64, device=sorted_keys.device)
-    cut = torch.searchsorted(_ordered(sorted_keys), _ordered(b), right=False)
+    cut = torch.searchsorted(_ordered(sorted_keys).contiguous(), _ordered(b), right=False)
     zero = torch.zeros(1, dtype=cut.dtype, device=cut.device)
     end = torch.full((1,), sorted_keys.numel(), dtype=cut.dtype, device=cut.device)
     return torch.cat([zero, cut, end])
 
 
-def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """All-to-all of (key, count) rows by key range.  `keys` ascending (unsigned), int64 storage.
-    Returns the rows this rank owns (concatenation of what every peer sent, peer order)."""
+def exchange_rows(rows: torch.Tensor, key_bits: int, extra: int = 0, group=None) -> Tuple[torch.Tensor, List[int]]:
+    """All-to-all of table rows by key range.  ``rows`` is (n, w) int64: the key's word(s) then the
+    count, ascending by key (unsigned; rows[:, 0] is the most significant word and ``key_bits`` the bits
+    it uses).  Returns (the rows this rank owns = what every peer sent, in peer order; every rank's
+    ``extra``).  Two collectives: the row counts (with ``extra`` riding along) and the rows."""
     world = dist.get_world_size(group)
     if world == 1:
-        return keys, counts
-    dev = keys.device
+        return rows, [int(extra)]
+    dev = rows.device
     if dev.type != "cpu" and dist.get_backend(group) == "gloo":
         # gloo moves host memory: stage through the CPU (test / single-GPU rehearsal path; with
         # backend "nccl" = RCCL the tensors stay on the device and travel over xGMI)
-        rk, rc = exchange_pairs(keys.cpu(), counts.cpu(), key_bits, group)
-        return rk.to(dev), rc.to(dev)
-    pts = split_points(keys, key_bits, world)
+        got, extras = exchange_rows(rows.cpu(), key_bits, extra, group)
+        return got.to(dev), extras
+    pts = split_points(rows[:, 0], key_bits, world)
     send = (pts[1:] - pts[:-1]).to(torch.int64)
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    send_l, recv_l = send.tolist(), recv.tolist()
-    out_k = torch.empty(int(sum(recv_l)), dtype=keys.dtype, device=keys.device)
-    out_c = torch.empty_like(out_k)
-    dist.all_to_all_single(out_k, keys, recv_l, send_l, group=group)
-    dist.all_to_all_single(out_c, counts, recv_l, send_l, group=group)
-    return out_k, out_c
+    meta = torch.stack([send, torch.full_like(send, int(extra))], dim=1).contiguous()
+    got_meta = torch.empty_like(meta)
+    dist.all_to_all_single(got_meta, meta, group=group)
+    got_meta = got_meta.cpu()
+    send_l, recv_l = send.tolist(), got_meta[:, 0].tolist()
+    out = torch.empty((int(sum(recv_l)), rows.shape[1]), dtype=rows.dtype, device=dev)
+    dist.all_to_all_single(out, rows.contiguous(), recv_l, send_l, group=group)
+    return out, [int(x) for x in got_meta[:, 1].tolist()]
 
 
-def merge_ranks(ctx, key_bits: int, group=None, device=None) -> int:
+def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, group=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One-word rows given as two arrays (kept for callers that hold them that way)."""
+    rows, _ = exchange_rows(torch.stack([keys, counts], dim=1), key_bits, 0, group)
+    return rows[:, 0].contiguous(), rows[:, 1].contiguous()
+
+
+def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0) -> int:
     """Re-partition ctx's running table across the ranks of `group` by key range and sum.
-    On return ctx holds exactly the rows of its own range (by-reference rows: all on rank 0).
-    Returns the number of rows this rank now owns."""
+    On return ctx holds exactly the packed rows of its own range; rows kept as text (characters
+    outside the alphabet, k > 64: rare) all sit on rank 0.  With ``min_count`` > 1 rows whose merged
+    count is below it are dropped at their owner (single-chunk samples: the filter comes after the
+    merge).  Returns the number of rows this rank now owns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
+        if min_count > 1:
+            ctx.filter_min(min_count)
         return ctx.rows()
     dev = device if device is not None else torch.device("cuda", ctx.device)
-    st = ctx.stats()
-    packed = st["mode_name"] in ("dense", "hash64")  # the other modes keep their rows as text
+    words = ctx.words_per_key()
+    packed = ctx.stats()["mode_name"] in ("dense", "hash64", "hash128")  # byref keeps every row as text
+    n = 0
+    cap = ctx.rows() + 1
+    keys = torch.empty((cap, words), dtype=torch.int64, device=dev)
+    cnts = torch.empty(cap, dtype=torch.int64, device=dev)
     if packed:
-        cap = ctx.rows() + 1
-        keys = torch.empty(cap, dtype=torch.int64, device=dev)
-        cnts = torch.empty(cap, dtype=torch.int64, device=dev)
         n = ctx.export_pairs_device(keys.data_ptr(), cnts.data_ptr(), cap)
-        keys, cnts = keys[:n], cnts[:n]
+    rows = torch.cat([keys[:n], cnts[:n, None]], dim=1)
     ex_k, ex_c = ctx.export_exotic()
     ctx.reset()
-    if packed:
-        rk, rc = exchange_pairs(keys, cnts, key_bits, group)
-        if rk.numel():
-            torch.cuda.synchronize(dev) if dev.type == "cuda" else None
-            ctx.import_pairs_device(rk.data_ptr(), rc.data_ptr(), rk.numel())
-    # by-reference rows (text keys) are rare: one small all_reduce tells whether any rank has some,
-    # and only then are they gathered (as objects) and summed on rank 0
-    red_dev = dev if dist.get_backend(group) != "gloo" else torch.device("cpu")
-    any_ref = torch.tensor([int(ex_c.size)], dtype=torch.int64, device=red_dev)
-    dist.all_reduce(any_ref, group=group)
-    if int(any_ref.item()):
-        gathered = [None] * world
-        dist.all_gather_object(gathered, (ex_k, ex_c), group=group)
+    got, extras = exchange_rows(rows, 64 if words == 2 else key_bits, int(ex_c.size), group)
+    if got.shape[0]:
+        rk = got[:, :words].contiguous()
+        rc = got[:, words].contiguous()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        ctx.import_pairs_device(rk.data_ptr(), rc.data_ptr(), got.shape[0])
+    # rows kept as text: gathered (as objects, through the host) to rank 0 only when some rank has any
+    if any(extras):
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object((ex_k, ex_c), gathered, dst=0, group=group)
         if rank == 0:
             for k_arr, c_arr in gathered:
                 ctx.import_exotic(k_arr, c_arr)
+    if min_count > 1:
+        ctx.filter_min(min_count)
     return ctx.rows()
+
+
+def record_ranges(text, parts: int) -> List[Tuple[int, int]]:
+    """Cut FASTA bytes into ``parts`` byte ranges of about equal size that start at record starts
+    (a line whose first character is '>'), so that no window spans a cut."""
+    mv = memoryview(text)
+    n = len(mv)
+    data = np.frombuffer(mv, dtype=np.uint8) if n else np.zeros(0, np.uint8)
+    cuts = [0]
+    for i in range(1, parts):
+        at = max(cuts[-1], n * i // parts)
+        while at < n:
+            nl = np.flatnonzero(data[at:min(n, at + (1 << 20))] == 0x0A)
+            hit = [int(at + j + 1) for j in nl.tolist() if at + j + 1 < n and data[at + j + 1] == 0x3E]
+            if hit:
+                at = hit[0]
+                break
+            at = min(n, at + (1 << 20))
+        cuts.append(min(at, n))
+    cuts.append(n)
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def count_single_chunk(ctx, text, min_count: int, key_bits: int, group=None, device=None) -> int:
+    """A sample that is one chunk, split over the ranks: rank r counts the r-th
+    record range of ``text`` (every rank holds the same bytes) WITHOUT a filter, the ranks merge, and
+    min_count is applied to the merged counts -- the reference applies it once per file
+    (lib/mercat2_kmers.py:73-76).  Text in front of the first header belongs to the first range (the
+    reference counts it as a record).  Returns the rows this rank owns afterwards."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    a, b = record_ranges(text, world)[rank]
+    ctx.reset()
+    ctx.count_chunk(memoryview(text)[a:b], 0 if world > 1 else min_count)
+    if world == 1:
+        return ctx.rows()
+    return merge_ranks(ctx, key_bits, group=group, device=device, min_count=min_count)

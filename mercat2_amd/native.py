@@ -14,7 +14,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 ALPHABET_NT2, ALPHABET_AA5, ALPHABET_RAW = 0, 1, 2
-MODE_NAMES = {0: "dense", 1: "hash64", 2: "ref128", 3: "byref"}
+MODE_NAMES = {0: "dense", 1: "hash64", 2: "hash128", 3: "byref"}
 
 MK_OK = 0
 ERR_NAMES = {-1: "MK_ERR_ARG", -2: "MK_ERR_HIP", -3: "MK_ERR_NOMEM", -4: "MK_ERR_STATE",
@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
     "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of", "mk_gunzip_parallel",
+    "mk_filter_min", "mk_remove_n", "mk_free",
 ]
 
 
@@ -62,6 +63,12 @@ class FileStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
+
+
+class CleanStats(C.Structure):
+    """mk_clean_stats_t (include/mercat_hip.h)."""
+    _fields_ = [(n, C.c_uint64) for n in ("gc_count", "total_length", "records", "split_records", "pieces", "n_runs")] + \
+               [("unsupported_record", C.c_int64)]
 
 
 class AlphaStats(C.Structure):
@@ -120,6 +127,9 @@ def lib() -> C.CDLL:
         "mk_merged_export": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t, szp]),
         "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
         "mk_trim": (C.c_int, [vp]),
+        "mk_filter_min": (C.c_int, [vp, C.c_uint64]),
+        "mk_remove_n": (C.c_int, [u8p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), szp, C.POINTER(CleanStats)]),
+        "mk_free": (None, [C.c_void_p]),
         "mk_alpha_stats": (C.c_int, [vp, C.POINTER(AlphaStats)]),
         "mk_gunzip_parallel": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "mk_crc32_of": (C.c_uint32, [u8p, C.c_size_t, C.c_uint32]),
@@ -169,6 +179,25 @@ def chunk_cuts(text, chunksize: int) -> np.ndarray:
         if rc != -7:
             raise MercatHipError(rc, "mk_chunk_cuts")
         cap = need.value
+
+
+def remove_n(text, toupper: bool = False) -> Tuple[bytes, dict]:
+    """mk_remove_n: (cleaned FASTA text, mk_clean_stats_t fields).  When ``unsupported_record`` >= 0 the text is
+    empty and the caller rewrites the file itself (mercat2_amd.fasta)."""
+    L = lib()
+    addr, n, keep = _buf_ptr(text)
+    out, out_len, st = C.c_void_p(), C.c_size_t(0), CleanStats()
+    rc = L.mk_remove_n(addr, n, 1 if toupper else 0, C.byref(out), C.byref(out_len), C.byref(st))
+    if rc == -7:
+        raise IndexError("list index out of range")  # header.split()[0] of an empty header (lib/mercat2_fasta.py:40-41)
+    if rc:
+        raise MercatHipError(rc, "mk_remove_n")
+    try:
+        data = C.string_at(out, out_len.value) if out.value else b""
+    finally:
+        if out.value:
+            L.mk_free(out)
+    return data, {n_: int(getattr(st, n_)) for n_, _ in st._fields_}
 
 
 def default_streams(k: int, alphabet: int) -> int:
@@ -389,6 +418,10 @@ class Counter:
     def trim(self):
         """Free the per-chunk working memory, keep the running table (mk_trim)."""
         self._check(self._L.mk_trim(self._h))
+
+    def filter_min(self, min_count: int):
+        """Drop rows whose count is below ``min_count`` (the filter of a one-chunk sample counted in pieces)."""
+        self._check(self._L.mk_filter_min(self._h, int(min_count)))
 
     def merge_from(self, other: "Counter"):
         """Add every row of ``other`` (same GPU, alphabet, k) into this context, on the device."""

@@ -82,3 +82,122 @@ def test_two_ranks_equal_one(k, c):
         return ks[ok].view("S%d" % k).reshape(-1)
     p0, p1 = packed(parts[0]), packed(parts[1])
     assert p0.size and p1.size and np.sort(p0)[-1] < np.sort(p1)[0]
+
+
+# ---------------------------------------------------------------- two-word keys travel on the device
+def _worker_k63(rank, port, k, c, out):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from mercat2_amd import native
+        from mercat2_amd import dist as mkdist
+
+        def no_objects(*a, **kw):  # clean reads have no text rows: nothing may be pickled
+            raise AssertionError("rows were sent as pickled objects")
+        dist.gather_object = dist.all_gather_object = no_objects
+        data = native.synth_reads(150_000, 31, 120_000, 150, 32).tobytes()
+        with native.Counter(k, native.ALPHABET_NT2, device=0) as ctx:
+            assert ctx.words_per_key() == 2
+            for a, b in _chunks(data)[rank::WORLD]:
+                ctx.count_chunk(memoryview(data)[a:b], c)
+            mkdist.merge_ranks(ctx, 2 * k, device=torch.device("cuda", 0))
+            kmers, counts = ctx.export()
+        out[rank] = (kmers, counts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,c", [(63, 2), (33, 1)])
+def test_two_word_keys_exchange_on_device(k, c):
+    """33..64-mers: rows are {hi, lo, count} on the device, re-partitioned by the range of hi with the same
+    all_to_all as one-word keys; rank order == key order."""
+    from mercat2_amd import native
+    data = native.synth_reads(150_000, 31, 120_000, 150, 32).tobytes()
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        for a, b in _chunks(data):
+            ctx.count_chunk(memoryview(data)[a:b], c)
+        want_k, want_c = ctx.export()
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker_k63, args=(port, k, c, out), nprocs=WORLD, join=True)
+        parts = [out[r] for r in range(WORLD)]
+    assert parts[0][1].size and parts[1][1].size
+    assert np.array_equal(np.concatenate([p[0] for p in parts]), want_k)  # concatenation in rank order is sorted
+    assert np.array_equal(np.concatenate([p[1] for p in parts]), want_c)
+
+
+# ------------------------------------------------ a one-chunk sample split over the ranks (filter after merge)
+def _worker_single(rank, port, k, c, out):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from mercat2_amd import native
+        from mercat2_amd import dist as mkdist
+        data = _data()
+        with native.Counter(k, native.ALPHABET_NT2, device=0) as ctx:
+            mkdist.count_single_chunk(ctx, data, c, 2 * k, device=torch.device("cuda", 0))
+            kmers, counts = ctx.export()
+        out[rank] = (kmers, counts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,c", [(31, 3), (21, 10), (63, 2), (5, 10)])
+def test_single_chunk_sample_split_over_ranks(k, c):
+    """record ranges, no per-range filter, min_count after the merge == the reference's
+    find_kmers on the whole file (lib/mercat2_kmers.py:73-76)."""
+    from mercat2_amd import native
+    data = _data()
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(data, c)  # one chunk, one filter
+        want_k, want_c = ctx.export()
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker_single, args=(port, k, c, out), nprocs=WORLD, join=True)
+        parts = [out[r] for r in range(WORLD)]
+    keys = np.concatenate([p[0].reshape(-1, k).view("S%d" % k).reshape(-1) for p in parts])
+    cnts = np.concatenate([p[1] for p in parts])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(keys[order], want_k.view("S%d" % k).reshape(-1))
+    assert np.array_equal(cnts[order], want_c)
+
+
+def test_record_ranges_cut_at_headers():
+    from mercat2_amd.dist import record_ranges
+    data = b"pre\nACGT\n>a\nAC\nGT\n>b x>y\nTTTT\n>c\n" + b"A" * 50 + b"\n>d\nC\n"
+    for parts in (1, 2, 3, 5, 9):
+        rr = record_ranges(data, parts)
+        assert rr[0][0] == 0 and rr[-1][1] == len(data) and all(a[1] == b[0] for a, b in zip(rr, rr[1:]))
+        for a, _ in rr[1:]:
+            assert a == len(data) or (data[a:a + 1] == b">" and data[a - 1:a] == b"\n")
+
+
+# ------------------------------------------------------------------ bench.py starts and proves its ranks
+def test_bench_launches_ranks_and_strong_rows_match(tmp_path):
+    """`bench.py --gpus 2` without a launcher starts two ranks itself (gloo rehearsal: both on the one GPU);
+    strong scaling (chunks of ONE sample dealt i mod N) ends with the rows of the 1-rank run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu", "--no-file-leg", "--reads", "2000000", "--genome", "1000000"]
+    env = dict(os.environ, MK_BENCH_BACKEND="gloo")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+
+    def run(extra):
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        return json.loads(lines[0])
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--scaling", "strong"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["ranks_seen"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["chunks"] >= 3
+    assert two["rows"] == one["rows"] > 0
+    assert two["also"]["scaling"] == "weak" and two["also"]["rows"] >= one["rows"]

@@ -386,7 +386,7 @@ def test_large_k_packed_by_reference_vs_c_oracle(k):
     with native.Counter(k, native.ALPHABET_NT2) as ctx:
         ctx.count_chunk(data, 2)
         kmers, counts = ctx.export()
-        assert ctx.stats()["mode_name"] == "ref128"  # mode 2: 33..64-mers (partitioned two-word keys or packed by-reference)
+        assert ctx.stats()["mode_name"] == "hash128"  # mode 2: 33..64-mers, two-word packed keys
     okm, ocn = c_oracle.count(data, k, 2)
     assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn)
 
