@@ -463,7 +463,7 @@ __device__ __forceinline__ unsigned skc_lane_rank(u64 mask) {  // set bits of ma
 // The top n (<= 64) deferred keys of this wave's stack: linear probing from the slot after the home slot
 // (the home slot is known to hold another key), one key per lane.
 __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* q, unsigned& qcount, unsigned n,
-                                          unsigned* s_overflow) {
+                                              unsigned* s_overflow) {
   const unsigned lane = threadIdx.x & 63;
   qcount -= n;
   if (lane < n) {
@@ -670,8 +670,10 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           STAMP_ADD(tC, t0);
           if (*(volatile unsigned*)ovf) over = true;  // hint only; decided after the barrier below
         }
+        STAMP_ADD(tA, t0);
         if (qcount) skc_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
         first_pass = false;
+        STAMP_ADD(tB, t0);
         __syncthreads();  // A: every insert of the pass is in the table
         STAMP_ADD(tF, t0);
         ++npass;
@@ -692,36 +694,29 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
           }
         }
-        // ---- emit (when complete) into the bucket's own region, and clear
+        // ---- emit (when complete) into the bucket's own region, and clear.  The sweep reads the COUNTS only
+        //      (two neighbouring slots per access) and the key of a slot only when its count reaches min_count
+        //      -- with -c 10 that is one slot in a hundred; a slot is occupied iff its count is not zero
         {
           constexpr int PER = SKC_SLOTS / SKC_THREADS;
-          u64 ek[PER];
+          static_assert(PER % 2 == 0, "the sweep takes slot pairs");
           unsigned ec[PER];
-          unsigned mine = 0, occ = 0;
-          // two neighbouring slots per access: 16-byte key and 8-byte count reads/writes halve the LDS
-          // instructions of this sweep (PER is even: SKC_SLOTS is a multiple of 2 * SKC_THREADS)
-          static_assert(PER % 2 == 0, "emit sweeps slot pairs");
+          unsigned keep = 0;  // bit q: slot q of this thread survives
+          unsigned occ = 0;
 #pragma unroll
           for (int q = 0; q < PER; q += 2) {
             const unsigned i = (q * SKC_THREADS + 2 * threadIdx.x);
-            const ulonglong2 kp = *reinterpret_cast<const ulonglong2*>(&tkey[i]);
             const uint2 cp = *reinterpret_cast<const uint2*>(&tcnt[i]);
-            *reinterpret_cast<ulonglong2*>(&tkey[i]) = make_ulonglong2(MK_EMPTY, MK_EMPTY);
-            *reinterpret_cast<uint2*>(&tcnt[i]) = make_uint2(0u, 0u);
-            ek[q] = kp.x;
-            ek[q + 1] = kp.y;
             ec[q] = cp.x;
             ec[q + 1] = cp.y;
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-              occ += ek[q + z] != MK_EMPTY;
-              if (over || ek[q + z] == MK_EMPTY || (u64)ec[q + z] < min_count) ek[q + z] = MK_EMPTY;
-              mine += ek[q + z] != MK_EMPTY;
-            }
+            occ += (cp.x != 0) + (cp.y != 0);
+            keep |= (!over && cp.x && (u64)cp.x >= min_count) ? (1u << q) : 0u;
+            keep |= (!over && cp.y && (u64)cp.y >= min_count) ? (2u << q) : 0u;
           }
           for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
-          if (mine) {
+          if (keep) {
+            unsigned mine = (unsigned)__popc(keep);
             const unsigned at = emitted + atomicAdd(&s_emit[par], mine);  // LDS cursor inside the region
             unsigned o = 0;
             if ((u64)at + mine > region) {  // only a region sized from a sampled histogram can be too small
@@ -730,12 +725,18 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             }
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
-              if (mine && ek[q] != MK_EMPTY) {
-                my_keys[at + o] = ek[q];
+              if (mine && ((keep >> q) & 1u)) {
+                my_keys[at + o] = tkey[(q & ~1) * SKC_THREADS + 2 * threadIdx.x + (q & 1)];
                 my_cnts[at + o] = ec[q];
                 ++o;
               }
             }
+          }
+#pragma unroll
+          for (int q = 0; q < PER; q += 2) {
+            const unsigned i = (q * SKC_THREADS + 2 * threadIdx.x);
+            *reinterpret_cast<ulonglong2*>(&tkey[i]) = make_ulonglong2(MK_EMPTY, MK_EMPTY);
+            *reinterpret_cast<uint2*>(&tcnt[i]) = make_uint2(0u, 0u);
           }
         }
         __syncthreads();  // B: table is clear, counters of this pass are final
@@ -926,7 +927,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     d = mk_dbg_ptr;
     if (d) { (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
       double a[7] = {0,0,0,0,0,0,0}; for (int w = 0; w < ncu; ++w) for (int q = 0; q < 7; ++q) a[q] += (double)h[w * 8 + q] / ncu;
-      fprintf(stderr, "[stamp] per-WG cycles: scan=%.0f expand=%.0f insert=%.0f emit=%.0f bucket_tail=%.0f other=%.0f passes=%.1f\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6]); }
+      fprintf(stderr, "[stamp] per-WG cycles: loop_exit=%.0f last_drain=%.0f insert=%.0f emit=%.0f bucket_tail=%.0f loads+barrierA=%.0f passes=%.1f\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6]); }
   }
 #endif
   MK_HIP(hipGetLastError());
