@@ -1,9 +1,13 @@
 """Command line of the counting path, flag-compatible with bin/mercat2.py (lines 41-50, 68-79,
 207-215, 253-283, 312-346, 411-448 of the reference): -i/-f/-k/-n/-c/-s/-o/-replace.
 
-Only the count phase is implemented here: inputs are FASTA (nucleotide or
-protein; plain or .gz). FASTQ conversion, N-cleaning, ORF calling, reports and plots belong to
-the reference's other layers and are not part of this engine.
+The count phase and what stands directly in front of and behind it: inputs are
+FASTA (nucleotide or protein; plain or .gz); nucleotide inputs go through removeN first unless
+-skipclean is given (bin/mercat2.py:239-244), exactly as in the reference; the combined tables are
+written after counting.  FASTQ conversion and QC, ORF calling (-prod / -fgs), reports, PCA and plots
+belong to the reference's other layers: their flags are accepted where they change nothing here
+(-lowmem, -pca, -debug, -category_file) and refused with a clear message where the run would need
+that layer's output (-prod, -fgs, FASTQ input).
 """
 from __future__ import annotations
 
@@ -15,8 +19,11 @@ import timeit
 from pathlib import Path
 
 from . import __version__
-from .harness import run_sample
+from .fasta import removeN_text
+from .harness import run_sample, run_text
 from .report import merge_counters
+
+FILE_EXT_FASTQ = [".fq", ".fastq", ".fq.gz", ".fastq.gz"]
 
 FILE_EXT_NUCLEOTIDE = [".fasta", ".fa", ".fna", ".ffn", ".fasta.gz", ".fa.gz", ".fna.gz", ".ffn.gz"]
 FILE_EXT_PROTEIN = [".faa", ".faa.gz"]
@@ -33,6 +40,15 @@ def parseargs(argv=None):
     p.add_argument("-s", type=int, default=100, required=False, help="Split into x MB files. [100]")
     p.add_argument("-o", type=str, default="mercat_results", required=False, help="Output folder")
     p.add_argument("-replace", action="store_true", help="Replace existing output directory [False]")
+    p.add_argument("-skipclean", action="store_true", help="skip trimming of the sequences [False]")
+    p.add_argument("-toupper", action="store_true", help="convert all input sequences to uppercase [False]")
+    # flags of the reference's other layers (bin/mercat2.py:45-58)
+    p.add_argument("-prod", action="store_true", help="(MerCat2: ORF calling with prodigal) not part of this engine")
+    p.add_argument("-fgs", action="store_true", help="(MerCat2: ORF calling with FragGeneScanRs) not part of this engine")
+    p.add_argument("-lowmem", action="store_true", help="(MerCat2: incremental PCA) accepted, no effect: no PCA here")
+    p.add_argument("-pca", action="store_true", help="(MerCat2: PCA plots) accepted, no effect")
+    p.add_argument("-debug", action="store_true", help=argparse.SUPPRESS)
+    p.add_argument("-category_file", type=str, required=False, help=argparse.SUPPRESS)
     p.add_argument("-gpu", type=int, default=0, help="HIP device index [0]")
     p.add_argument("-streams", type=int, default=None,
                    help="engine contexts counting chunks concurrently [2 for one-word keys, else 1]")
@@ -47,6 +63,9 @@ def parseargs(argv=None):
             p.error(f"file '{filename}' is not valid.\n")
     if args.f and not os.path.isdir(args.f):
         p.error(f"folder {args.f} is not valid.\n")
+    if args.prod or args.fgs:
+        p.error("-prod / -fgs call ORFs with prodigal / FragGeneScanRs before counting amino-acid k-mers; that layer is "
+                "not part of this engine: run the ORF caller and pass its .faa output with -i / -f")
     return args, p
 
 
@@ -59,6 +78,10 @@ def classify(path: Path):
         if cand in FILE_EXT_NUCLEOTIDE + FILE_EXT_PROTEIN:
             ext = cand
     if not ext:
+        for i in reversed(range(len(suffixes))):
+            if "".join(suffixes[i:]) in FILE_EXT_FASTQ:
+                raise SystemExit(f"'{path.name}': FASTQ input needs MerCat2's fastq_to_fasta layer (fastp / fastqc), which is "
+                                 "not part of this engine; convert it to FASTA first")
         return None, None
     base = path.name[: -len(ext)]
     return ("protein" if ext in FILE_EXT_PROTEIN else "nucleotide"), base
@@ -98,12 +121,22 @@ def main(argv=None) -> int:
         workers = max(1, min(int(args.n), 8, len(samples[kind])))
         threads = max(2, 16 // workers)  # reader/decoder threads per sample: about 16 in all
 
+        clean = kind == "nucleotide" and not args.skipclean
+
         def one(item):
             base, f = item
             lines = []
-            run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
-                       streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables,
-                       threads=threads if workers > 1 else 0)
+            if clean:
+                # removeN, then count the cleaned text straight from memory; the size of <base>_clean.fna.gz on
+                # disk decides about chunking, as it does in the reference (bin/mercat2.py:101, 243)
+                clean_file, _gc, cleaned = removeN_text(f, out / "clean", args.toupper)
+                chunked = args.s > 0 and os.stat(clean_file).st_size >= args.s * 1024 * 1024
+                run_text(base, cleaned, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, chunked,
+                         device=args.gpu, streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables)
+            else:
+                run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
+                           streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables,
+                           threads=threads if workers > 1 else 0)
             return lines
         if workers == 1:
             results = map(one, samples[kind].items())

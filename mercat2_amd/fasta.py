@@ -83,15 +83,23 @@ def clean_text(raw, toupper: bool = False) -> Tuple[bytes, Dict[str, float]]:
     return cleaned, {"GC Content": 100.0 * st["gc_count"] / st["total_length"]}
 
 
-def removeN(fasta: Path, outpath: Path, toupper: bool):
-    """Splits sequences in a scaffold fasta file at N repeats (lib/mercat2_fasta.py:53-119: same arguments, same
-    ``(path of <base>_clean.fna.gz, {'GC Content': ...})`` result, same file content).  The file is written with
-    Python's gzip module exactly as the reference writes it (level 9), so that its size -- which decides whether
-    the sample is chunked, bin/mercat2.py:101 -- is the same."""
+def removeN_text(fasta: Path, outpath: Path, toupper: bool):
+    """removeN that also hands back the cleaned text: ``(path, stats, cleaned bytes)`` -- the counting path takes
+    the bytes from memory instead of inflating the file it has just written."""
     os.makedirs(outpath, exist_ok=True)
     basename = Path(fasta).stem.split(".")[0]
     out_fasta = Path(outpath, f"{basename}_clean.fna.gz")
     cleaned, stats = clean_text(read_fasta_bytes(fasta), toupper)
     with gzip.open(out_fasta, "wb") as writer:
         writer.write(cleaned)
-    return out_fasta.absolute(), stats
+        writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
+    return out_fasta.absolute(), stats, cleaned
+
+
+def removeN(fasta: Path, outpath: Path, toupper: bool):
+    """Splits sequences in a scaffold fasta file at N repeats (lib/mercat2_fasta.py:53-119: same arguments, same
+    ``(path of <base>_clean.fna.gz, {'GC Content': ...})`` result, same file content).  The file is written with
+    Python's gzip module exactly as the reference writes it (level 9), so that its size -- which decides whether
+    the sample is chunked, bin/mercat2.py:101 -- is the same."""
+    path, stats, _ = removeN_text(fasta, outpath, toupper)
+    return path, stats

@@ -99,6 +99,53 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
         return _finish(ctx, basename, out_file)
 
 
+def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib: int = 100, chunked: bool = False,
+             *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, report=print,
+             keep: Optional[dict] = None, alphabet: Optional[int] = None) -> Tuple[str, Optional[os.PathLike]]:
+    """run_sample for FASTA bytes already in memory (e.g. the text removeN just produced, mercat2_amd.fasta):
+    ``chunked`` says whether the reference would have chunked the file these bytes stand for (its on-disk size
+    against -s, bin/mercat2.py:101); if so the Chunker's cut rule is applied to the bytes and every chunk is
+    counted with its own min_count filter, the chunks dealt to ``streams`` contexts."""
+    from concurrent.futures import ThreadPoolExecutor
+    from .chunker import chunk_offsets
+    mv = memoryview(text)
+    if alphabet is None:
+        alphabet = guess_alphabet("", bytes(mv[:4096]))
+    chunk_bytes = max(0, int(chunk_mib)) * 1024 * 1024
+    offs = chunk_offsets(mv, chunk_bytes) if (chunked and chunk_bytes > 0) else [0, len(mv)]
+    spans = list(zip(offs[:-1], offs[1:]))
+    if streams is None:
+        streams = native.default_streams(kmer, alphabet)
+    n = max(1, min(int(streams), len(spans)))
+    canon = bool(canonical and alphabet == native.ALPHABET_NT2)
+    key = (kmer, alphabet, device, canon)
+    ctxs = [_take_context(*key) for _ in range(n)]
+    size = 1 << 62
+    try:
+        def share(i):
+            for a, b in spans[i::n]:
+                ctxs[i].count_chunk(mv[a:b], min_count)
+        if n == 1:
+            share(0)
+        else:
+            with ThreadPoolExecutor(n) as pool:
+                list(pool.map(share, range(n)))
+            for c in ctxs[1:]:
+                ctxs[0].merge_from(c)
+        size = len(mv)
+        result = _finish(ctxs[0], basename, out_file, report)
+        if keep is not None and result[1] is not None:
+            ctxs[0].trim()
+            keep[basename] = ctxs.pop(0)
+        return result
+    except BaseException:
+        size = 1 << 62
+        raise
+    finally:
+        for c in ctxs:
+            _give_back(c, key, size)
+
+
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
                *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, threads: int = 0,
                stats: Optional[dict] = None, report=print, keep: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:

@@ -1,0 +1,64 @@
+"""removeN (lib/mercat2_fasta.py:53-119) through the native rewrite (mk_remove_n) and mercat2_amd.fasta, against
+outputs of the reference's own function (tests/golden/make_clean_golden.py; for the five genomes these are also
+the reference's committed results/2023-11-29/fna-5genomes_gz-10/clean/*_clean.fna.gz, byte for byte)."""
+import gzip
+import hashlib
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN, read_input
+from mercat2_amd import fasta, native
+
+CASES = json.loads((GOLDEN / "clean_cases.json").read_text())
+
+
+@pytest.mark.parametrize("case", sorted(CASES), ids=sorted(CASES))
+def test_clean_text_matches_reference(case):
+    c = CASES[case]
+    text, stats = fasta.clean_text(read_input(c["input"]), c["toupper"])
+    assert len(text) == c["bytes"] and text.count(b"\n") == c["lines"]
+    assert hashlib.sha256(text).hexdigest() == c["sha256"]
+    assert stats["GC Content"] == c["gc"]  # same integers, same division
+    small = GOLDEN / "clean" / ("%s_%s.fna" % (c["out_name"][:-len("_clean.fna.gz")], "upper" if c["toupper"] else "asis"))
+    if small.exists():
+        assert text == small.read_bytes()
+
+
+@pytest.mark.parametrize("case", ["RW1.fna.gz|asis", "Scaffolds_with-NNN.fna.gz|upper", "edge_clean.fa|asis", "edge_clean_odd.fa|upper"])
+def test_removeN_file_like_the_reference(case, tmp_path):
+    """Same path, same decompressed bytes, same size on disk (the size decides whether the sample is chunked,
+    bin/mercat2.py:101: the file is written with the same gzip settings)."""
+    c = CASES[case]
+    out, stats = fasta.removeN(GOLDEN / "inputs" / c["input"], tmp_path / "clean", c["toupper"])
+    assert out == (tmp_path / "clean" / c["out_name"]).absolute()
+    assert hashlib.sha256(gzip.open(out, "rb").read()).hexdigest() == c["sha256"]
+    assert os.stat(out).st_size == c["gz_size"]
+    assert stats == {"GC Content": c["gc"]}
+
+
+def test_native_path_is_the_one_used():
+    """The native rewrite handles every golden input but the one with word breaks inside split sequences."""
+    for case, c in CASES.items():
+        _, st = native.remove_n(read_input(c["input"]), c["toupper"])
+        assert (st["unsupported_record"] >= 0) == (c["input"] == "edge_clean_odd.fa"), case
+
+
+def test_reference_errors_are_kept():
+    with pytest.raises(ZeroDivisionError):
+        fasta.clean_text(b"", False)
+    with pytest.raises(ZeroDivisionError):
+        fasta.clean_text(b"no header at all\nACGT\n", False)
+    with pytest.raises(IndexError):
+        fasta.clean_text(b">\nACGTNNACGT\n", False)  # header.split()[0] of an empty header
+
+
+def test_committed_clean_file_is_reproduced():
+    """RW1.fna.gz -> RW1_clean.fna.gz, the pair the reference committed (the other four: digests in clean.json)."""
+    text, _ = fasta.clean_text(read_input("RW1.fna.gz"), False)
+    assert text == read_input("RW1_clean.fna.gz")
+    want = json.loads((GOLDEN / "clean.json").read_text())
+    for name, w in want.items():
+        got, _ = fasta.clean_text(read_input(name), False)
+        assert (len(got), hashlib.sha256(got).hexdigest()) == (w["bytes"], w["sha256"]), name

@@ -320,6 +320,44 @@ def test_cli_writes_reference_tsv(tmp_path, capsys):
     assert "No significant k-mers found" in capsys.readouterr().out
 
 
+def test_cli_nucleotide_default_runs_removeN_first(tmp_path, capsys):
+    """Without -skipclean a nucleotide FASTA goes through removeN before counting (bin/mercat2.py:239-244): the
+    reference's committed run on RW1.fna.gz (k=5, -c 10) left clean/RW1_clean.fna.gz and tsv_nucleotide/
+    RW1_counts.tsv; both are reproduced.  With -skipclean the raw file is counted (find_kmers on RW1.fna.gz)."""
+    import gzip
+    import shutil
+    from mercat2_amd import cli
+    src = tmp_path / "RW1.fna.gz"
+    shutil.copyfile(GOLDEN / "inputs" / "RW1.fna.gz", src)
+    out = tmp_path / "res"
+    assert cli.main(["-i", str(src), "-k", "5", "-c", "10", "-o", str(out), "-lowmem", "-pca"]) == 0
+    assert gzip.open(out / "clean" / "RW1_clean.fna.gz", "rb").read() == read_input("RW1_clean.fna.gz")
+    assert (out / "tsv_nucleotide" / "RW1_counts.tsv").read_text() == (GOLDEN / "tsv" / "ref_RW1_clean_k5_c10.tsv").read_text()
+    out2 = tmp_path / "res2"
+    assert cli.main(["-i", str(src), "-k", "5", "-c", "10", "-o", str(out2), "-skipclean"]) == 0
+    assert not (out2 / "clean").exists()
+    want = EXPECTED["RW1.fna.gz|k5|c10"]
+    text = (out2 / "tsv_nucleotide" / "RW1_counts.tsv").read_text()
+    assert hashlib.sha256(text.encode()).hexdigest() == want["sha256"]
+    # Scaffolds_with-NNN: N runs, lower case; -toupper turns the lower-case bases into countable ones
+    src2 = tmp_path / "Scaffolds_with-NNN.fna"
+    src2.write_bytes(read_input("Scaffolds_with-NNN.fna.gz"))
+    for flags, upper in ((["-toupper"], True), ([], False)):
+        out3 = tmp_path / ("res3_%d" % upper)
+        assert cli.main(["-i", str(src2), "-k", "5", "-c", "10", "-o", str(out3)] + flags) == 0
+        cleaned = gzip.open(out3 / "clean" / "Scaffolds_with-NNN_clean.fna.gz", "rb").read()
+        table = cpu_ref.count_text(cleaned, 5, 10)
+        assert (out3 / "tsv_nucleotide" / "Scaffolds_with-NNN_counts.tsv").read_text() == cpu_ref.tsv_text("Scaffolds_with-NNN", table)
+    capsys.readouterr()
+    for bad in (["-prod"], ["-fgs"]):
+        with pytest.raises(SystemExit):
+            cli.main(["-i", str(src), "-k", "5", "-o", str(tmp_path / "x")] + bad)
+    fq = tmp_path / "reads.fastq"
+    fq.write_text("@r\nACGT\n+\nIIII\n")
+    with pytest.raises(SystemExit):
+        cli.main(["-i", str(fq), "-k", "5", "-o", str(tmp_path / "y")])
+
+
 def _fold_filter(table, c):
     return {key: n for key, n in cpu_ref.canonical_fold(table).items() if n >= c}
 
