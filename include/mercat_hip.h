@@ -145,6 +145,10 @@ int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* matri
  * names are the column titles, in the order of ctxs (the reference sorts the sample names). */
 int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
                         const char* path, size_t* rows);
+/* merge_tsv_T (lib/mercat2_report.py:160-194), the transposed table beta diversity reads (bin/mercat2.py:354-355):
+ * "sample\t<k-mer>\t...\n", then "<names[s]>\t<count>...\n" per sample.  The reference orders the k-mer columns
+ * as a Python set iterates (not reproducible); here they are in sorted(str) order.  *rows = k-mer columns. */
+int mk_write_merged_tsv_t(mk_ctx* const* ctxs, int n, const char* const* names, const char* path, size_t* rows);
 /* ---- alpha diversity of a sample: the moments of its count column (lib/mercat2_diversity.py:13-53
  *      computes nine scikit-bio metrics from exactly these), reduced on the GPU ------------------ */
 typedef struct mk_alpha_t {

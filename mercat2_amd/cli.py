@@ -21,7 +21,7 @@ from pathlib import Path
 from . import __version__
 from .fasta import removeN_text
 from .harness import run_sample, run_text
-from .report import merge_counters
+from .report import merge_counters, merge_counters_T
 
 FILE_EXT_FASTQ = [".fq", ".fastq", ".fq.gz", ".fastq.gz"]
 
@@ -152,7 +152,9 @@ def main(argv=None) -> int:
         # straight from the tables; samples without significant k-mers are left out, as there
         try:
             if tables:
-                merge_counters(tables, out / ("combined_Nucleotide.tsv" if kind == "nucleotide" else "combined_protein.tsv"))
+                stem = "combined_Nucleotide" if kind == "nucleotide" else "combined_protein"
+                merge_counters(tables, out / (stem + ".tsv"))
+                merge_counters_T(tables, out / (stem + "_T.tsv"))  # bin/mercat2.py:154-157, read by beta diversity
         finally:
             for t in tables.values():
                 t.close()

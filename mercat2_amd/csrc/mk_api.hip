@@ -901,6 +901,57 @@ extern "C" int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const
   return MK_OK;
 }
 
+// merge_tsv_T (lib/mercat2_report.py:160-194): the same matrix with samples as rows: "sample\t<k-mers>\n", then one
+// line per sample.  The reference lists the k-mer columns in the iteration order of a Python set (different in
+// every process); here they are sorted.  Consumers address columns by label (bin/mercat2.py:354-355).
+extern "C" int mk_write_merged_tsv_t(mk_ctx* const* ctxs, int n, const char* const* names, const char* path, size_t* rows_out) {
+  if (!ctxs || n < 1 || !ctxs[0] || !names || !path) return MK_ERR_ARG;
+  mk_ctx* c = ctxs[0];
+  const size_t k = (size_t)c->k;
+  std::vector<uint8_t> kmers;
+  std::vector<u64> matrix;  // rows x n
+  int rc = merged_samples(ctxs, n, [&](const uint8_t* s, const u64* counts) {
+    kmers.insert(kmers.end(), s, s + k);
+    matrix.insert(matrix.end(), counts, counts + n);
+  });
+  if (rc) return rc;
+  const size_t rows = k ? kmers.size() / k : 0;
+  FILE* f = fopen(path, "wb");
+  if (!f) { c->err = std::string("mk_write_merged_tsv_t: cannot open ") + path; return MK_ERR_IO; }
+  std::vector<char> out;
+  out.reserve(1 << 22);
+  auto flush = [&]() {
+    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+  };
+  const char* head = "sample";
+  out.insert(out.end(), head, head + 6);
+  for (size_t r = 0; r < rows; ++r) {
+    out.push_back('\t');
+    out.insert(out.end(), (const char*)kmers.data() + r * k, (const char*)kmers.data() + (r + 1) * k);
+    if (out.size() > (1u << 22) - 4096 - k) flush();
+  }
+  out.push_back('\n');
+  for (int s = 0; s < n; ++s) {
+    const char* nm = names[s] ? names[s] : "";
+    out.insert(out.end(), nm, nm + strlen(nm));
+    for (size_t r = 0; r < rows; ++r) {
+      out.push_back('\t');
+      u64 v = matrix[r * (size_t)n + (size_t)s];
+      char num[24];
+      int len = 0;
+      do { num[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+      while (len) out.push_back(num[--len]);
+      if (out.size() > (1u << 22) - 4096) flush();
+    }
+    out.push_back('\n');
+  }
+  flush();
+  const bool bad = ferror(f) != 0;
+  if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_merged_tsv_t: write failed: ") + path; return MK_ERR_IO; }
+  if (rows_out) *rows_out = rows;
+  return MK_OK;
+}
+
 // ------------------------------------------------------------------------ alpha diversity
 extern "C" int mk_alpha_stats(mk_ctx* c, mk_alpha_t* out) {
   if (!c || !out) return MK_ERR_ARG;

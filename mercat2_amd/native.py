@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
     "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of", "mk_gunzip_parallel",
-    "mk_filter_min", "mk_remove_n", "mk_free",
+    "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t",
 ]
 
 
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
                                     C.POINTER(FileStats)]),
         "mk_merged_export": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t, szp]),
         "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
+        "mk_write_merged_tsv_t": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, szp]),
         "mk_trim": (C.c_int, [vp]),
         "mk_filter_min": (C.c_int, [vp, C.c_uint64]),
         "mk_remove_n": (C.c_int, [u8p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), szp, C.POINTER(CleanStats)]),
@@ -285,6 +286,16 @@ def write_merged_tsv(ctxs: Sequence["Counter"], names: Sequence[str], path, firs
     cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
     rows = C.c_size_t(0)
     ctxs[0]._check(L.mk_write_merged_tsv(arr, len(ctxs), cn, first_column.encode(), os.fsencode(str(path)), C.byref(rows)))
+    return rows.value
+
+
+def write_merged_tsv_T(ctxs: Sequence["Counter"], names: Sequence[str], path) -> int:
+    """mk_write_merged_tsv_t: the file merge_tsv_T (lib/mercat2_report.py:160-194) writes, columns sorted."""
+    L = lib()
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    rows = C.c_size_t(0)
+    ctxs[0]._check(L.mk_write_merged_tsv_t(arr, len(ctxs), cn, os.fsencode(str(path)), C.byref(rows)))
     return rows.value
 
 

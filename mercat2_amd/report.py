@@ -1,5 +1,6 @@
-"""Drop-in for the table-merging step of lib/mercat2_report.py (``merge_tsv``, lines 98-156): the
-combined sample x k-mer table that feeds the reference's plots, PCA and beta diversity.
+"""Drop-in for the table-merging step of lib/mercat2_report.py (``merge_tsv``, lines 98-156, and
+``merge_tsv_T``, lines 160-194): the combined sample x k-mer table that feeds the reference's plots
+and PCA, and its transpose that beta diversity reads.
 
 ``merge_counters`` builds it straight from the samples' tables on the GPU (no TSV re-read);
 ``merge_tsv`` keeps the reference's signature (a dict of TSV paths) by loading the files into engine
@@ -24,6 +25,15 @@ def merge_counters(counters: Dict[str, "native.Counter"], out_file, first_column
     return native.write_merged_tsv([counters[n] for n in names], names, out_file, first_column)
 
 
+def merge_counters_T(counters: Dict[str, "native.Counter"], out_file) -> int:
+    """The transposed table (samples as rows) of ``{sample name: Counter}``; returns the number of k-mer columns.
+    Columns are in sorted k-mer order (the reference's order is that of a Python set: arbitrary)."""
+    names = sorted(counters.keys())
+    if not names:
+        raise ValueError("merge_counters_T: no samples")
+    return native.write_merged_tsv_T([counters[n] for n in names], names, out_file)
+
+
 def _load_tsv(path) -> tuple:
     """(first header field, kmers (rows, k) uint8, counts uint64) of a count table."""
     with open(path, "rb") as fh:
@@ -40,8 +50,18 @@ def _load_tsv(path) -> tuple:
     return head, flat, counts
 
 
+def merge_tsv_T(tsv_list: Dict[str, os.PathLike], out_file: os.PathLike, *, device: int = 0) -> None:
+    """merge_tsv_T(tsv_list, out_file) of lib/mercat2_report.py:160-194 (same arguments): ``sample`` + one column per
+    k-mer of any sample, one row per sample (sorted names), 0 where a sample lacks the k-mer."""
+    _merge_files(tsv_list, out_file, device, transposed=True)
+
+
 def merge_tsv(tsv_list: Dict[str, os.PathLike], out_file: os.PathLike, *, device: int = 0) -> None:
     """merge_tsv(tsv_list, out_file) of lib/mercat2_report.py:98-156 (same arguments)."""
+    _merge_files(tsv_list, out_file, device, transposed=False)
+
+
+def _merge_files(tsv_list, out_file, device: int, transposed: bool) -> None:
     names = sorted(tsv_list.keys())
     header: Optional[str] = None
     ctxs = []
@@ -57,7 +77,10 @@ def merge_tsv(tsv_list: Dict[str, os.PathLike], out_file: os.PathLike, *, device
             c = native.Counter(k, native.ALPHABET_RAW, device)
             ctxs.append(c)
             c.import_exotic(kmers, counts)
-        native.write_merged_tsv(ctxs, names, out_file, header or "k-mer")
+        if transposed:
+            native.write_merged_tsv_T(ctxs, names, out_file)
+        else:
+            native.write_merged_tsv(ctxs, names, out_file, header or "k-mer")
     finally:
         for c in ctxs:
             c.close()

@@ -105,3 +105,45 @@ def test_rows_of_a_combined_table_committed_by_the_reference(tmp_path):
     last = max(want)
     got = {key: int(v) for key, v in zip(keys, matrix[:, 0]) if key <= last and v}
     assert got == {key: v for key, v in want.items() if v}
+
+
+def test_merge_tsv_and_merge_tsv_T_against_the_reference_functions(tmp_path):
+    """merge_tsv / merge_tsv_T (lib/mercat2_report.py:98-156, 160-194) with the reference's signatures against the
+    outputs of the reference's own functions (tests/golden/make_report_golden.py): the merged table byte for byte;
+    the transposed one as the same header set and the same matrix -- its columns are in sorted order here, in the
+    order of a Python set there."""
+    import json
+    idx = json.loads((GOLDEN / "report" / "transposed.json").read_text())
+    for case, g in idx.items():
+        tsv_list = {name: str(GOLDEN / rel) for name, rel in g["inputs"].items()}
+        m = tmp_path / (case + "_m.tsv")
+        report.merge_tsv(tsv_list, m)
+        assert m.read_text() == (GOLDEN / "report" / (case + "_merged.tsv")).read_text()
+        t = tmp_path / (case + "_t.tsv")
+        report.merge_tsv_T(tsv_list, t)
+        lines = t.read_text().split("\n")
+        assert lines[-1] == "" and lines[0].split("\t") == ["sample"] + g["columns_sorted"]
+        assert [ln.split("\t")[0] for ln in lines[1:-1]] == g["sample_order"]
+        for ln in lines[1:-1]:
+            cells = ln.split("\t")
+            assert cells[1:] == g["rows"][cells[0]], (case, cells[0])
+
+
+def test_transposed_table_from_engine_tables(tmp_path):
+    samples = _inputs()
+    k = 21
+    tables = {n: cpu_ref.count_text(d, k, 2) for n, d in samples.items()}
+    ctxs = {}
+    try:
+        for n, d in samples.items():
+            ctxs[n] = native.Counter(k, native.ALPHABET_NT2)
+            ctxs[n].count_chunk(d, 2)
+        out = tmp_path / "combined_T.tsv"
+        cols = report.merge_counters_T(ctxs, out)
+        keys = sorted(set().union(*[set(t) for t in tables.values()]))
+        assert cols == len(keys)
+        want = ["sample\t" + "\t".join(keys)] + [n + "\t" + "\t".join(str(tables[n].get(key, 0)) for key in keys) for n in sorted(tables)]
+        assert out.read_text() == "\n".join(want) + "\n"
+    finally:
+        for c in ctxs.values():
+            c.close()
