@@ -29,8 +29,9 @@ extern "C" {
 #define MK_ERR_HIP (-2)       /* a HIP runtime call failed (message has the call and hipError) */
 #define MK_ERR_NOMEM (-3)     /* device or host allocation failed */
 #define MK_ERR_STATE (-4)     /* call sequence error (feed outside begin/end, ...) */
-#define MK_ERR_NON_ASCII (-5) /* input holds bytes >= 0x80: the reference would decode them as
-                                 multi-byte characters; refused rather than counted wrongly */
+#define MK_ERR_NON_ASCII (-5) /* a SEQUENCE line holds bytes >= 0x80: the reference would decode them as
+                                 multi-byte characters; refused rather than counted wrongly.  Header lines
+                                 may hold any bytes: they never enter a k-mer */
 #define MK_ERR_IO (-6)        /* file could not be written */
 #define MK_ERR_RANGE (-7)     /* caller buffer too small / value out of range */
 
@@ -145,6 +146,13 @@ int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* matri
  * names are the column titles, in the order of ctxs (the reference sorts the sample names). */
 int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
                         const char* path, size_t* rows);
+/* The same file with the rows exactly as merge_tsv's streaming loop produces them: that loop looks for the next k-mer
+ * only among the samples that advanced in the current step and writes a sample's pending count under the k-mer at
+ * hand whenever its own key is not greater (lib/mercat2_report.py:131-150), so a key held only by samples that did
+ * not advance gets no row of its own and its count lands in a later row.  Tables that share (nearly) all their keys
+ * -- k = 5 over genomes, the reference's committed runs -- come out the same either way. */
+int mk_write_merged_tsv_as_reference(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
+                                     const char* path, size_t* rows);
 /* merge_tsv_T (lib/mercat2_report.py:160-194), the transposed table beta diversity reads (bin/mercat2.py:354-355):
  * "sample\t<k-mer>\t...\n", then "<names[s]>\t<count>...\n" per sample.  The reference orders the k-mer columns
  * as a Python set iterates (not reproducible); here they are in sorted(str) order.  *rows = k-mer columns. */

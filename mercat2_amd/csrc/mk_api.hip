@@ -354,7 +354,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   }
   if (c->h_info->non_ascii) {
     c->err = "input holds " + std::to_string(c->h_info->non_ascii) +
-             " byte(s) >= 0x80 (non-ASCII text is not supported; the chunk was not counted)";
+             " sequence byte(s) >= 0x80 (non-ASCII sequence text is not supported; the chunk was not counted)";
     return MK_ERR_NON_ASCII;
   }
   const size_t seq_len = (size_t)c->h_info->seq_len;
@@ -802,9 +802,15 @@ struct RowIter {  // the rows of one sample in sorted(str) order
   }
 };
 
-// f(kmer, counts[n]) for every k-mer present in any sample, in sorted order; absent = 0
+// f(kmer, counts[n]) for every k-mer present in any sample, in sorted order; absent = 0.
+// as_reference: the rows exactly as merge_tsv's streaming loop produces them (lib/mercat2_report.py:128-152).  That
+// loop picks the next k-mer only among the samples that ADVANCED in the current step (:131, :149-150) and, for a
+// sample whose current key is not greater than the k-mer being written, writes that sample's count whatever its
+// key is (:137-140).  So a key held only by samples that did not advance is never written as a row of its own: its
+// count lands in a later row.  With as_reference the same rows come out (tables that share nearly all their keys --
+// k = 5 on genomes -- are not affected); without it the table is the true union.
 template <class F>
-int merged_samples(mk_ctx* const* ctxs, int n, F&& f) {
+int merged_samples(mk_ctx* const* ctxs, int n, F&& f, bool as_reference = false) {
   if (!ctxs || n < 1 || !ctxs[0]) return MK_ERR_ARG;
   mk_ctx* c0 = ctxs[0];
   for (int s = 0; s < n; ++s) {
@@ -824,6 +830,27 @@ int merged_samples(mk_ctx* const* ctxs, int n, F&& f) {
   const size_t k = (size_t)c0->k;
   std::vector<u64> row((size_t)n);
   std::vector<uint8_t> key(k + 1);
+  if (as_reference) {
+    const uint8_t* best = nullptr;
+    for (int s = 0; s < n; ++s)
+      if (it[s].cur && (!best || memcmp(it[s].cur, best, k) < 0)) best = it[s].cur;
+    if (!best) return MK_OK;
+    memcpy(key.data(), best, k);
+    std::vector<uint8_t> next(k + 1);
+    for (;;) {
+      bool have_next = false;
+      for (int s = 0; s < n; ++s) {
+        if (!it[s].cur || memcmp(it[s].cur, key.data(), k) > 0) { row[s] = 0; continue; }
+        row[s] = it[s].cnt;  // (whatever this sample's key is: see above)
+        it[s].next();
+        if (it[s].cur && (!have_next || memcmp(it[s].cur, next.data(), k) < 0)) { memcpy(next.data(), it[s].cur, k); have_next = true; }
+      }
+      f(key.data(), row.data());
+      if (!have_next) break;
+      key.swap(next);
+    }
+    return MK_OK;
+  }
   for (;;) {
     const uint8_t* best = nullptr;
     for (int s = 0; s < n; ++s)
@@ -860,8 +887,18 @@ extern "C" int mk_merged_export(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint
   return MK_OK;
 }
 
+static int write_merged(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column, const char* path,
+                        size_t* rows_out, bool as_reference);
 extern "C" int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
                                    const char* path, size_t* rows_out) {
+  return write_merged(ctxs, n, names, first_column, path, rows_out, false);
+}
+extern "C" int mk_write_merged_tsv_as_reference(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column,
+                                                const char* path, size_t* rows_out) {
+  return write_merged(ctxs, n, names, first_column, path, rows_out, true);
+}
+static int write_merged(mk_ctx* const* ctxs, int n, const char* const* names, const char* first_column, const char* path,
+                        size_t* rows_out, bool as_reference) {
   if (!ctxs || n < 1 || !ctxs[0] || !names || !first_column || !path) return MK_ERR_ARG;
   mk_ctx* c = ctxs[0];
   FILE* f = fopen(path, "wb");
@@ -892,7 +929,7 @@ extern "C" int mk_write_merged_tsv(mk_ctx* const* ctxs, int n, const char* const
     out.push_back('\n');
     ++rows;
     if (out.size() > (1u << 22) - 4096 - k - 24 * (size_t)n) flush();
-  });
+  }, as_reference);
   flush();
   const bool bad = ferror(f) != 0;
   if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_merged_tsv: write failed: ") + path; return MK_ERR_IO; }

@@ -45,7 +45,7 @@ struct __attribute__((aligned(32))) MkSlot128 {
 struct MkChunkInfo {
   unsigned long long seq_len;       // bytes in seq (symbols + separators)
   unsigned long long symbols;       // kept sequence characters
-  unsigned long long non_ascii;     // bytes >= 0x80 seen in raw
+  unsigned long long non_ascii;     // kept (sequence) bytes >= 0x80; header lines may hold any bytes
   unsigned long long bad_symbols;   // kept characters outside the alphabet
   unsigned long long windows;       // windows counted by the packed/dense path
   unsigned long long exotic;        // windows counted by the by-reference path

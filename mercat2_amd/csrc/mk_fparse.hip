@@ -55,11 +55,12 @@ __device__ __forceinline__ uint4 classify16(const uint8_t* __restrict__ raw, siz
     v = make_uint4(w0, w1, w2, w3);
   }
   nl = gt = st = low = 0;
-  hi = 0;
+  hi = 0;  // mask of the bytes >= 0x80 (only the emit pass uses it: there it is known which bytes are kept)
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));  // no array: stays in registers
-    hi += __popc(xd & 0x80808080u);
+    // bits 7, 15, 23, 31 -> bits 0..3: the multiply lines them up at bits 21..24
+    hi |= (((((xd & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * d);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const unsigned c = (xd >> (8 * e)) & 0xFFu;
@@ -123,13 +124,12 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
   const int lane = threadIdx.x & 63;
   const size_t base = wave * FP_WAVE_BYTES;
   unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
-  unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0, nhi = 0;
+  unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0;
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
     unsigned nl, gt, st, low, hi;
     (void)classify16(raw, pos, begin, n, nl, gt, st, low, hi);
-    nhi += hi;
     unsigned out, sep, bl, last_nl;
     const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
     c0 += __popc(out);
@@ -151,14 +151,12 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
   for (int d = 32; d > 0; d >>= 1) {
     c0 += __shfl_down(c0, d);
     c1 += __shfl_down(c1, d);
-    nhi += __shfl_down(nhi, d);
   }
   const bool any_low = __ballot(flag_low != 0) != 0;
   if (lane == 0) {
     entries[wave].a = any_nl | (s0 << 1);
     entries[wave].b = c0 | (c1 << 16);
     if (any_low) atomicOr(&info->parse_fallback, 1ull);
-    if (nhi) atomicAdd(&info->non_ascii, (u64)nhi);
   }
 }
 
@@ -271,6 +269,8 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   unsigned state = sc.st;
   unsigned filled = 0;   // bytes emitted so far by this wave
   unsigned nsym = 0;
+  unsigned nhi = 0;      // KEPT bytes >= 0x80: sequence characters the reference would decode as multi-byte text
+                         // (bytes of header lines never enter a k-mer: lib/mercat2_kmers.py:52-53)
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
     prev_nl = last_nl;
     const unsigned cnt = __popc(out);
     nsym += cnt - __popc(sep);
+    nhi += __popc(hi & out & ~sep);
     unsigned inc = cnt;  // inclusive scan over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -368,6 +369,10 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   }
   for (int d = 32; d > 0; d >>= 1) nsym += __shfl_down(nsym, d);
   if (lane == 0) scan[wave].pad = nsym;  // summed by mk_fparse_total (no hot atomic)
+  if (__ballot(nhi != 0)) {  // (never, for ASCII input)
+    for (int d = 32; d > 0; d >>= 1) nhi += __shfl_down(nhi, d);
+    if (lane == 0) atomicAdd(&info->non_ascii, (u64)nhi);
+  }
 }
 
 __global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict__ scan, size_t nwaves,

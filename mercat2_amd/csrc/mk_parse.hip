@@ -229,10 +229,10 @@ __global__ __launch_bounds__(PT) void mk_parse_emit(const uint8_t* __restrict__ 
       size_t i = base + j;
       if (i >= n) break;
       unsigned ch = b[j], out;
-      hi += ch >> 7;
       if (pstep(q, ch, raw, i, n, out)) {
         seq[off++] = (uint8_t)out;
         syms += (out != MK_SEP);
+        hi += (out != MK_SEP) & (ch >> 7);  // kept characters only: header bytes never enter a k-mer
       }
     }
   }

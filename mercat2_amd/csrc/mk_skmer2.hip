@@ -29,8 +29,10 @@
 #define SK2_MAX_P1 (1 << SK2_MAX_P1_LOG2)
 #define SK2_NKMAX 8
 #ifndef SK2C_SLOTS
-#define SK2C_SLOTS 7168   // 20 bytes each: 140 KB of LDS; the most a 1024-thread sweep divides (4096: 25 % slower at k = 63, twice the sub-range passes)
+#define SK2C_SLOTS 6144   // 20 bytes each: 120 KB of LDS, + 32 KB of deferred-key stacks (4096: 25 % slower at k = 63, twice the sub-range passes)
 #endif
+#define SK2C_WAVES (SK2C_THREADS / 64)
+#define SK2C_QCAP 128     // deferred keys a wave can hold: < 64 left over + one slot x 64 lanes pushed at once
 #define SK2C_THREADS 1024
 #define SK2C_TARGET (SK2C_SLOTS * 6 / 10)
 #define SK2C_LOADCAP (SK2C_SLOTS * 3 / 4)
@@ -269,22 +271,29 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 }
 
 // ------------------------------------------------------------------------------------- count
+// Slot hash of a two-word key: six full-rate 24-bit multiplies over its 24-bit pieces (a 32-bit multiply issues at a
+// quarter of the rate; see skc_hash in mk_skmer.hip).  Bits 31.. pick the slot, bits 15..0 the sub-range.
 __device__ __forceinline__ unsigned sk2c_hash(u64 hi, u64 lo) {
-  unsigned h = (unsigned)hi * 0x9E3779B1u ^ (unsigned)(hi >> 32) * 0x85EBCA77u;
-  h ^= ((unsigned)lo * 0xC2B2AE3Du ^ (unsigned)(lo >> 32) * 0x27D4EB2Fu) + (h << 6) + (h >> 2);
-  h ^= h >> 15;
-  h *= 0x2C1B3C6Du;
-  h ^= h >> 16;
-  return h;
+  const unsigned h0 = (unsigned)hi, h1 = (unsigned)(hi >> 32), l0 = (unsigned)lo, l1 = (unsigned)(lo >> 32);
+  unsigned h = __umul24(h0, 0x9E3779u) ^ __umul24(__funnelshift_r(h0, h1, 24), 0x85EBCBu) ^ __umul24(h1 >> 16, 0xC2B2AFu);
+  h ^= __umul24(l0, 0x27D4EBu) ^ __umul24(__funnelshift_r(l0, l1, 24), 0x165667u) ^ __umul24(l1 >> 16, 0x2C1B3Du);
+  return h ^ (h >> 15);
 }
 
 // Home slot of a hash (any table size).
 __device__ __forceinline__ unsigned sk2c_home(unsigned h) { return (unsigned)(((u64)h * SK2C_SLOTS) >> 32); }
 
-// Insert one 128-bit key (see the protocol in the header).
+__device__ __forceinline__ unsigned sk2c_lane_rank(u64 mask) {  // set bits of mask below this lane
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// Insert one 128-bit key, probing from its home slot (see the protocol in the header).  The lane that wins a slot
+// writes the key and publishes inside the loop iteration in which it won.
 __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
   unsigned slot = sk2c_home(h);
-  for (int probe = 0; probe < SK2C_MAX_PROBE;) {
+  bool done = false;
+#pragma unroll 1
+  for (int probe = 0; probe < SK2C_MAX_PROBE && !done;) {
     unsigned c = __hip_atomic_load(&tcnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (c == 0) {
       c = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
@@ -293,19 +302,32 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
         tlo[slot] = lo;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
-        return;
+        done = true;
       }
     }
-    if (c & SK2C_LOCK) continue;  // another lane is writing this slot: look again
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (thi[slot] == hi && tlo[slot] == lo) {
-      atomicAdd(&tcnt[slot], 1u);
-      return;
+    if (!done && !(c & SK2C_LOCK)) {  // (a slot that is being written is looked at again)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (thi[slot] == hi && tlo[slot] == lo) {
+        atomicAdd(&tcnt[slot], 1u);
+        done = true;
+      } else {
+        slot = slot + 1 == SK2C_SLOTS ? 0u : slot + 1;
+        ++probe;
+      }
     }
-    slot = slot + 1 == SK2C_SLOTS ? 0u : slot + 1;
-    ++probe;
   }
-  atomicOr(ovf, 1u);
+  if (!done) atomicOr(ovf, 1u);
+}
+
+// The top n (<= 64) deferred keys of this wave's stack, one per lane, through the general insert.
+__device__ __forceinline__ void sk2c_drain(u64* thi, u64* tlo, unsigned* tcnt, const ulonglong2* q, unsigned& qcount, unsigned n,
+                                           unsigned* ovf) {
+  const unsigned lane = threadIdx.x & 63;
+  qcount -= n;
+  if (lane < n) {
+    const ulonglong2 key = q[qcount + lane];
+    sk2c_insert(thi, tlo, tcnt, ovf, key.x, key.y, sk2c_hash(key.x, key.y));
+  }
 }
 
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
@@ -318,6 +340,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
   __shared__ u64 thi[SK2C_SLOTS];
   __shared__ u64 tlo[SK2C_SLOTS];
   __shared__ unsigned tcnt[SK2C_SLOTS];
+  __shared__ __attribute__((aligned(16))) ulonglong2 wq[SK2C_WAVES][SK2C_QCAP];  // deferred keys, one stack per wave
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
   __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
@@ -357,8 +380,14 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
         const unsigned sel_shift = SK2C_SUB_BITS - s;
         unsigned* const ovf = &s_overflow[par];
         u64 win_pass = 0;
-        for (u64 j = threadIdx.x; j < n; j += SK2C_THREADS) {
-          const Sk2Rec rec = src[j];
+        ulonglong2* const myq = wq[threadIdx.x >> 6];
+        unsigned qcount = 0;  // this wave's deferred keys (wave-uniform)
+        // (the whole wave walks the record loop together: lanes past the end hold an empty record)
+        for (u64 jb = 0; jb < n; jb += SK2C_THREADS) {
+          const u64 j = jb + threadIdx.x;
+          Sk2Rec rec;
+          rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
+          if (j < n) rec = src[j];
           const int nk = (int)rec.nk;  // <= SK2_NKMAX
           win_pass += counted ? 0 : (u64)nk;
           u64 khi[SK2_NKMAX], klo[SK2_NKMAX];
@@ -378,12 +407,13 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
               alive |= mine ? (1u << u) : 0u;
             }
           }
-          // batched first probe: states of the 8 home slots, claims of the free ones, then the key
-          // compares of the occupied ones; whatever is left (collision, or a slot mid-write) takes
-          // the serial loop, which starts again at the home slot
+          // batched first probe: states of the 8 home slots, claims of the free ones, then the key compares of the
+          // occupied ones.  Whatever does not settle at its home slot (another key there, a slot mid-write, a lost
+          // claim) is DEFERRED onto the wave's stack and probed 64 keys at a time, every lane busy.
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u)
             st[u] = ((alive >> u) & 1u) ? __hip_atomic_load(&tcnt[sk2c_home(hh[u])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+          unsigned defer = 0;
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (((alive >> u) & 1u) && st[u] == 0) {
@@ -394,8 +424,10 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
                 tlo[slot] = klo[u];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
-                alive &= ~(1u << u);
+              } else {
+                defer |= 1u << u;  // somebody else took the slot meanwhile
               }
+              alive &= ~(1u << u);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -410,10 +442,22 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (!((alive >> u) & 1u)) continue;
             if (!(st[u] & SK2C_LOCK) && oh[u] == khi[u] && ol[u] == klo[u]) atomicAdd(&tcnt[sk2c_home(hh[u])], 1u);
-            else sk2c_insert(thi, tlo, tcnt, ovf, khi[u], klo[u], hh[u]);
+            else defer |= 1u << u;
+          }
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            const bool f = (defer >> u) & 1u;
+            const u64 m = __ballot(f);
+            if (m) {
+              if (f) myq[qcount + sk2c_lane_rank(m)] = make_ulonglong2(khi[u], klo[u]);
+              qcount += (unsigned)__popcll(m);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              if (qcount >= 64) sk2c_drain(thi, tlo, tcnt, myq, qcount, 64u, ovf);
+            }
           }
           if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
+        if (qcount) sk2c_drain(thi, tlo, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
         __syncthreads();  // A
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "mk_import_exotic", "mk_words_per_key", "mk_merge_from", "mk_set_profiling", "mk_get_stats", "mk_reset_stats",
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
     "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of", "mk_gunzip_parallel",
-    "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t",
+    "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t", "mk_write_merged_tsv_as_reference",
 ]
 
 
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
                                     C.POINTER(FileStats)]),
         "mk_merged_export": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t, szp]),
         "mk_write_merged_tsv": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
+        "mk_write_merged_tsv_as_reference": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, C.c_char_p, szp]),
         "mk_write_merged_tsv_t": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(C.c_char_p), C.c_char_p, szp]),
         "mk_trim": (C.c_int, [vp]),
         "mk_filter_min": (C.c_int, [vp, C.c_uint64]),
@@ -279,13 +280,16 @@ def merged_export(ctxs: Sequence["Counter"]) -> Tuple[np.ndarray, np.ndarray]:
     return kmers, matrix
 
 
-def write_merged_tsv(ctxs: Sequence["Counter"], names: Sequence[str], path, first_column: str = "k-mer") -> int:
-    """mk_write_merged_tsv: the file merge_tsv (lib/mercat2_report.py:98-156) writes, from the tables."""
+def write_merged_tsv(ctxs: Sequence["Counter"], names: Sequence[str], path, first_column: str = "k-mer",
+                     as_reference: bool = False) -> int:
+    """mk_write_merged_tsv: the combined table of merge_tsv (lib/mercat2_report.py:98-156) from the tables -- the true
+    union, or with ``as_reference`` the rows exactly as the reference's streaming loop writes them (see the header)."""
     L = lib()
     arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
     cn = (C.c_char_p * len(names))(*[n.encode() for n in names])
     rows = C.c_size_t(0)
-    ctxs[0]._check(L.mk_write_merged_tsv(arr, len(ctxs), cn, first_column.encode(), os.fsencode(str(path)), C.byref(rows)))
+    fn = L.mk_write_merged_tsv_as_reference if as_reference else L.mk_write_merged_tsv
+    ctxs[0]._check(fn(arr, len(ctxs), cn, first_column.encode(), os.fsencode(str(path)), C.byref(rows)))
     return rows.value
 
 

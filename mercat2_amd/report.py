@@ -4,8 +4,15 @@ and PCA, and its transpose that beta diversity reads.
 
 ``merge_counters`` builds it straight from the samples' tables on the GPU (no TSV re-read);
 ``merge_tsv`` keeps the reference's signature (a dict of TSV paths) by loading the files into engine
-tables first.  Both write the same text as the reference: header ``<first column>\\t<sorted names>``,
-then every k-mer present in any sample in sorted order with 0 where a sample lacks it.
+tables first.  Header ``<first column>\\t<sorted names>``, then one row per k-mer.
+
+Which rows: the reference's streaming merge looks for the next k-mer only among the samples that advanced in
+the current step and writes a sample's pending count under the k-mer at hand whenever its own key is not
+greater (lib/mercat2_report.py:131-150) -- a key held only by samples that did not advance gets no row of its
+own and its count lands in a later row.  ``merge_tsv`` (the reference's name) and the CLI write exactly those
+rows (``as_reference=True``), so the file is the one MerCat2 writes; ``as_reference=False`` gives the true union
+(every k-mer of any sample, 0 where a sample lacks it).  For tables that share nearly all their keys -- k = 5
+over genomes, the reference's committed runs -- the two are the same.  ``merge_tsv_T`` has no such quirk.
 """
 from __future__ import annotations
 
@@ -17,12 +24,13 @@ import numpy as np
 from . import native
 
 
-def merge_counters(counters: Dict[str, "native.Counter"], out_file, first_column: str = "k-mer") -> int:
-    """Write the combined table of ``{sample name: Counter}``; returns the number of k-mer rows."""
+def merge_counters(counters: Dict[str, "native.Counter"], out_file, first_column: str = "k-mer",
+                   as_reference: bool = True) -> int:
+    """Write the combined table of ``{sample name: Counter}``; returns the number of rows written."""
     names = sorted(counters.keys())
     if not names:
         raise ValueError("merge_counters: no samples")
-    return native.write_merged_tsv([counters[n] for n in names], names, out_file, first_column)
+    return native.write_merged_tsv([counters[n] for n in names], names, out_file, first_column, as_reference)
 
 
 def merge_counters_T(counters: Dict[str, "native.Counter"], out_file) -> int:
@@ -80,7 +88,7 @@ def _merge_files(tsv_list, out_file, device: int, transposed: bool) -> None:
         if transposed:
             native.write_merged_tsv_T(ctxs, names, out_file)
         else:
-            native.write_merged_tsv(ctxs, names, out_file, header or "k-mer")
+            native.write_merged_tsv(ctxs, names, out_file, header or "k-mer", as_reference=True)
     finally:
         for c in ctxs:
             c.close()

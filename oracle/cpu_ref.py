@@ -217,6 +217,42 @@ def count_sample_text(data: bytes, k: int, min_count: int, chunk_mib: int) -> Di
     return count_text(data, k, min_count)
 
 
+def merge_tsv_text(tables: Dict[str, Dict[str, int]], first: str = "k-mer") -> str:
+    """The text merge_tsv writes for ``{sample name: table}`` (lib/mercat2_report.py:98-156), restated with its
+    streaming loop as it is: the next k-mer is looked for only among the samples that advanced in the current step
+    (:131, :149-150), and a sample whose pending key is not greater than the k-mer at hand has its count written
+    under that k-mer, whatever its own key is (:137-140).  Pinned by tests/golden/report/*_merged.tsv."""
+    names = sorted(tables)
+    rows = {n: sorted(tables[n].items()) for n in names}
+    pos = {n: 0 for n in names}
+    out = [first + "\t" + "\t".join(names) + "\n"]
+    kmer = sorted(rows[n][0][0] for n in names)[0]  # (an empty table makes the reference raise IndexError, too)
+    while True:
+        line = [kmer]
+        nxt = set()
+        for n in names:
+            if pos[n] >= len(rows[n]) or rows[n][pos[n]][0] > kmer:
+                line.append("0")
+            else:
+                line.append(str(rows[n][pos[n]][1]))
+                pos[n] += 1
+                if pos[n] < len(rows[n]):
+                    nxt.add(rows[n][pos[n]][0])
+        out.append("\t".join(line) + "\n")
+        if not nxt:
+            break
+        kmer = sorted(nxt)[0]
+    return "".join(out)
+
+
+def union_tsv_text(tables: Dict[str, Dict[str, int]], first: str = "k-mer") -> str:
+    """The true union table: every k-mer of any sample in sorted order, 0 where a sample lacks it."""
+    names = sorted(tables)
+    keys = sorted(set().union(*[set(t) for t in tables.values()])) if tables else []
+    return first + "\t" + "\t".join(names) + "\n" + "".join(
+        key + "\t" + "\t".join(str(tables[n].get(key, 0)) for n in names) + "\n" for key in keys)
+
+
 def canonical_fold(table: Dict[str, int]) -> Dict[str, int]:
     """Opt-in extension (not reference behaviour): fold each ACGT key onto
     min(key, reverse-complement).  Keys with other letters are kept as they are."""

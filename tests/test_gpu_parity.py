@@ -185,6 +185,25 @@ def test_non_ascii_is_refused():
         assert ctx.to_dict() == {"ACG": 1, "CGT": 1}
 
 
+def test_non_ascii_in_header_lines_is_fine():
+    """Header text never enters a k-mer (lib/mercat2_kmers.py:52-53): a FASTA whose '>' lines hold UTF-8 is
+    counted like the reference counts it; only non-ASCII SEQUENCE characters are refused.  Both parsers."""
+    head = ">contig_1 Caf\u00e9 M\u00fcller \u4e2d\u6587\n".encode("utf-8")
+    data = head + b"ACGTACGTTGCA\nACGT\n" + ">r2 \u00e9\n".encode("utf-8") + b"TTGACC\n"
+    plain = b">contig_1 x\nACGTACGTTGCA\nACGT\n>r2 y\nTTGACC\n"
+    general = data.replace(b"ACGTACGTTGCA\n", b"ACGT ACGTTGCA\n")  # a blank inside a sequence line: the general parser
+    for k in (3, 5):
+        for alpha in (native.ALPHABET_NT2, native.ALPHABET_RAW):
+            with native.Counter(k, alpha) as ctx:
+                ctx.count_chunk(data, 1)
+                assert ctx.to_dict() == cpu_ref.count_text(plain, k, 1)
+                ctx.reset()
+                ctx.count_chunk(general, 1)
+                assert ctx.to_dict() == cpu_ref.count_text(plain.replace(b"ACGTACGTTGCA\n", b"ACGT ACGTTGCA\n"), k, 1)
+                with pytest.raises(native.NonAsciiInput):
+                    ctx.count_chunk(data + "AC\u00e9GT\n".encode("utf-8"), 1)
+
+
 def test_reset_and_reuse():
     a, b = read_input("A.fasta"), read_input("B.fasta")
     with native.Counter(21, native.ALPHABET_NT2) as ctx:

@@ -51,8 +51,11 @@ def test_merged_table_matches_union_of_sample_tables(tmp_path, k, alphabet):
             ctxs[n].count_chunk(d, 2)
             ctxs[n].trim()       # working memory released, the table stays
         out = tmp_path / "combined.tsv"
-        rows = report.merge_counters(ctxs, out)
+        rows = report.merge_counters(ctxs, out, as_reference=False)  # the true union
         assert out.read_text() == _expected_text(tables)
+        out_ref = tmp_path / "combined_ref.tsv"
+        report.merge_counters(ctxs, out_ref)                         # as MerCat2's merge_tsv writes it
+        assert out_ref.read_text() == cpu_ref.merge_tsv_text(tables)
         assert rows == len(set().union(*[set(t) for t in tables.values()]))
         names = sorted(ctxs)
         kmers, matrix = native.merged_export([ctxs[n] for n in names])
@@ -80,7 +83,7 @@ def test_merge_tsv_keeps_the_reference_signature(tmp_path):
         tables[n] = cpu_ref.count_text(d, 5, 3)
     out = tmp_path / "combined_Nucleotide.tsv"
     report.merge_tsv(paths, out)
-    assert out.read_text() == _expected_text(tables)
+    assert out.read_text() == cpu_ref.merge_tsv_text(tables)  # the rows of the reference's streaming loop
 
 
 def test_rows_of_a_combined_table_committed_by_the_reference(tmp_path):
@@ -105,6 +108,30 @@ def test_rows_of_a_combined_table_committed_by_the_reference(tmp_path):
     last = max(want)
     got = {key: int(v) for key, v in zip(keys, matrix[:, 0]) if key <= last and v}
     assert got == {key: v for key, v in want.items() if v}
+
+
+def test_combined_table_committed_by_the_reference_row_for_row(tmp_path):
+    """The same committed table, now with all five proteomes among the fixtures: the reference's run
+    (results/run-tests.sh: -k 5 -c 10 -s 1 on data/5-genomes-faa) chunked four of them at 1 MiB (per-chunk filter)
+    and merged the five tables with merge_tsv.  Header + first 400 rows must come out line for line -- including the
+    rows its streaming loop writes twice (only the first header field differs: that release wrote 'kmer')."""
+    gold = (GOLDEN / "combined_protein_k5_c10_head.tsv").read_text().splitlines()
+    names = ["DJ_pro", "GIC31_pro", "RW1_pro", "RW2_pro", "Rleg_pro"]
+    assert gold[0].split("\t")[1:] == names
+    ctxs = {}
+    try:
+        for n in names:
+            src = tmp_path / (n + ".faa")
+            src.write_bytes(gzip.open(GOLDEN / "inputs" / (n + ".faa.gz"), "rb").read())
+            ctxs[n] = native.Counter(5, native.ALPHABET_AA5)
+            native.count_file([ctxs[n]], src, 1 << 20, 10)
+        out = tmp_path / "combined_protein.tsv"
+        report.merge_counters(ctxs, out, first_column="kmer")
+        got = out.read_text().splitlines()
+        assert got[:len(gold)] == gold
+    finally:
+        for c in ctxs.values():
+            c.close()
 
 
 def test_merge_tsv_and_merge_tsv_T_against_the_reference_functions(tmp_path):
