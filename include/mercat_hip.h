@@ -81,7 +81,11 @@ int mk_reset(mk_ctx* ctx);
 /* Opt-in extension, NOT reference behaviour (the reference counts forward-strand substrings,
  * lib/mercat2_kmers.py:56-60): with on != 0 every ACGT-only window is counted under
  * min(kmer, reverse-complement(kmer)).  Windows holding other characters keep their own text.
- * Nucleotide alphabet only; call before the first chunk of a sample (or right after mk_reset). */
+ * Nucleotide alphabet only; call before the first chunk of a sample (or right after mk_reset).
+ * LIMIT: k <= 32 (one-word keys).  For 33 <= k <= 64 the call returns MK_ERR_ARG: the two-word path files a
+ * window under the minimizer of its FIRST 32 bases, which a window and its reverse complement do not share, so
+ * the two strands of a k-mer would meet in different buckets (a strand-symmetric minimizer over both ends of the
+ * window is not built).  k > 64 and the raw alphabet count text, which has no complement. */
 int mk_set_canonical(mk_ctx* ctx, int on);
 
 /* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */

@@ -16,11 +16,10 @@
 //     running table, the export and the multi-GPU merge are the ones the other large-k paths use.
 // Reference semantics: lib/mercat2_kmers.py:56-60 (every window +1), :73-76 (count >= min_count
 // per chunk).
-#include "mk_common.h"
-#include "mk_device.h"
+#include "mk_skmer_dev.h"
 #include <cstdlib>
 
-#define SK2_R 32
+#define SK2_R SK_R
 #define SK2_HIST_THREADS 1024   // (two 64 KB LDS histograms per workgroup: one workgroup per CU)
 #define SK2_SCAT_THREADS 1024
 #ifndef SK2_MAX_P1_LOG2
@@ -42,85 +41,13 @@
 
 static size_t div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
-// ---- shared with mk_skmer.hip (same definitions; kept local to this translation unit) -----------
-#define SK_M 11
-#define SK_MASK ((1u << (2 * SK_M)) - 1)
-__device__ __forceinline__ unsigned sk2_order_hash(unsigned mm) {
-  unsigned h = (__umul24(mm, 0x9277B5u) + 0x2C5A3Du) & SK_MASK;  // 24-bit multiply: full rate (see mk_skmer.hip)
-  h ^= h >> 11;
-  return h;
-}
-__device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return (mm * 0xC2B2AE3Du) >> (32 - p1_log2); }
-__device__ __forceinline__ unsigned sk2_mmer(u64 w0, u64 w1, int q) {
-  u64 x;
-  if (q == 0) x = w0;
-  else if (q < 32) x = (w0 << (2 * q)) | (w1 >> (64 - 2 * q));
-  else x = w1 << (2 * (q - 32));
-  return (unsigned)(x >> (64 - 2 * SK_M));
-}
-
-struct Sk2Runs {
-  unsigned valid, starts;
-  u64 pos[4];
-};
-
-// Minimizer (over the 22 candidate 11-mers of the window's first 32 bases) of every window, runs.
-__device__ __forceinline__ Sk2Runs sk2_analyse(u64 w0, u64 w1, unsigned valid) {
-  constexpr int W = 22, NQ = SK2_R + W - 1, P = 16;
-  unsigned ord[NQ];
-  {
-    unsigned mm = sk2_mmer(w0, w1, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (q) {
-        const int pos = q + SK_M - 1;
-        const unsigned base = (unsigned)((pos < 32 ? (w0 >> (62 - 2 * pos)) : (w1 >> (62 - 2 * (pos - 32)))) & 3u);
-        mm = ((mm << 2) | base) & SK_MASK;
-      }
-      ord[q] = (sk2_order_hash(mm) << 6) | (unsigned)q;
-    }
-  }
-#pragma unroll
-  for (int step = 1; step < P; step <<= 1) {
-#pragma unroll
-    for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
-  }
-  Sk2Runs r;
-  r.valid = valid;
-  r.starts = 0;
-  r.pos[0] = r.pos[1] = r.pos[2] = r.pos[3] = 0;
-  unsigned prev_pos = 64;
-#pragma unroll
-  for (int j = 0; j < SK2_R; ++j) {
-    const bool ok = (valid >> j) & 1u;
-    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
-    r.starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
-    prev_pos = ok ? best : 64u;
-    r.pos[j / 10] |= (u64)best << (6 * (j % 10));
-  }
-  return r;
-}
-
+// The minimizer of a window is taken over the 22 candidate 11-mers of its FIRST 32 bases: the analysis is the
+// k = 32 instantiation of mk_skmer_dev.h's.
+typedef SkRuns Sk2Runs;
+__device__ __forceinline__ Sk2Runs sk2_analyse(u64 w0, u64 w1, unsigned valid) { return sk_analyse<22>(w0, w1, valid, false); }
 template <class F>
-__device__ __forceinline__ void sk2_walk(const Sk2Runs& r, u64 w0, u64 w1, F&& emit) {
-  unsigned todo = r.starts;
-  while (todo) {
-    const int j = __ffs(todo) - 1;
-    todo &= todo - 1;
-    const unsigned stop = (r.starts | ~r.valid) & ~((2u << j) - 1);
-    int nk = (stop ? (__ffs(stop) - 1) : SK2_R) - j;
-    const u64 pw = j < 10 ? r.pos[0] : (j < 20 ? r.pos[1] : (j < 30 ? r.pos[2] : r.pos[3]));
-    const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
-    const unsigned mm = sk2_mmer(w0, w1, (int)best);
-    int at = j;
-    while (nk > 0) {
-      const int take = nk < SK2_NKMAX ? nk : SK2_NKMAX;
-      emit(at, take, mm);
-      at += take;
-      nk -= take;
-    }
-  }
-}
+__device__ __forceinline__ void sk2_walk(const Sk2Runs& r, u64 w0, u64 w1, F&& emit) { sk_walk(r, w0, w1, SK2_NKMAX, false, emit); }
+__device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return sk_bucket(mm, p1_log2); }
 
 // Windows j = 0..31 whose k (<= 64) bases are clean; p0 is a multiple of 32.
 __device__ __forceinline__ unsigned sk2_valid32(const u64* __restrict__ bad, size_t p0, int k) {

@@ -598,6 +598,111 @@ def test_full_size_properties_config3():
     assert np.all(cn10 <= cn1[pos]) and np.all(cn10 >= 10) and 0 < keys10.size < keys1.size
 
 
+def _revcomp_rows(km):
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    return comp[km[:, ::-1]]
+
+
+def test_full_size_properties_config3_canonical():
+    """BASELINE config 3 as it is worded (canonical k-mers; an opt-in extension here) at full size: S2 in
+    its 16 reference chunks.  (a) at c=1 the counts sum to the number of windows; (b) every key is the smaller of
+    itself and its reverse complement, rows strictly ascending; (c) the table is the forward-strand table of the same
+    chunks folded key by key onto min(key, revcomp) -- the definition of the mode -- checked in full; (d) at c=10
+    (per chunk) every row exists at c=1 with a count no larger."""
+    k = 31
+    data = native.synth_reads(10_000_000, 3, 10_000_000, 150, 4)
+    offs = chunk_offsets(data, 100 * 1024 * 1024)
+    view = memoryview(data)
+    spans = list(zip(offs[:-1], offs[1:]))
+    with native.Counter(k, native.ALPHABET_NT2, canonical=True) as ctx:
+        for lo, hi in spans:
+            ctx.count_chunk(view[lo:hi], 1)
+        kmc, cnc = ctx.export()
+        st = ctx.stats()
+    assert int(cnc.sum()) == 10_000_000 * (150 - k + 1) == st["windows"]
+    keys = kmc.view("S%d" % k).reshape(-1)
+    assert np.all(keys[:-1] < keys[1:])
+    rc = np.ascontiguousarray(_revcomp_rows(kmc)).view("S%d" % k).reshape(-1)
+    assert np.all(keys <= rc)
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        for lo, hi in spans:
+            ctx.count_chunk(view[lo:hi], 1)
+        kmf, cnf = ctx.export()
+    fkeys = kmf.view("S%d" % k).reshape(-1)
+    frc = np.ascontiguousarray(_revcomp_rows(kmf)).view("S%d" % k).reshape(-1)
+    folded = np.where(frc < fkeys, frc, fkeys)
+    uniq, inv = np.unique(folded, return_inverse=True)
+    summed = np.zeros(uniq.size, dtype=np.uint64)
+    np.add.at(summed, inv, cnf)
+    assert np.array_equal(uniq, keys) and np.array_equal(summed, cnc)
+    del kmf, cnf, fkeys, frc, folded, uniq, inv, summed
+    with native.Counter(k, native.ALPHABET_NT2, canonical=True) as ctx:
+        for lo, hi in spans:
+            ctx.count_chunk(view[lo:hi], 10)
+        km10, cn10 = ctx.export()
+    keys10 = km10.view("S%d" % k).reshape(-1)
+    pos = np.searchsorted(keys, keys10)
+    assert np.all(pos < keys.size) and np.array_equal(keys[pos], keys10)
+    assert np.all(cn10 <= cnc[pos]) and np.all(cn10 >= 10) and 0 < keys10.size < keys.size
+
+
+def test_full_size_properties_config5(tmp_path):
+    """BASELINE config 5 at its full size: 50 M x 150 bp from a 50 Mbp genome (S3, seeds 6/7), k=63, -c 10 -s 100,
+    streamed from a file through mk_count_file (reader threads -> pinned blocks -> chunks on the GPU, never the
+    whole sample in HBM).  (a) the Chunker rule gives the chunks of the text (78); every window is counted
+    (50 M x 88); the rows that survive -c 10 per chunk are in strictly ascending order; (b) device memory in use
+    after the 8 GB sample is bounded by the per-chunk working set, far below the sample; (c) linearity at c=1 on the
+    sample's first 100 MiB cut into 32 MiB chunks (55 M rows): the file counted as a whole == its chunks counted one by
+    one and summed, and the counts sum to the windows; (d) the same chunks at c=2 (per chunk) are a subset with counts
+    no larger."""
+    import torch
+    k, reads = 63, 50_000_000
+    data = native.synth_reads(50_000_000, 6, reads, 150, 7)
+    path = tmp_path / "S3.fna"
+    with open(path, "wb") as f:
+        f.write(memoryview(data))
+    first = chunk_offsets(memoryview(data)[:220 * 1024 * 1024], 100 * 1024 * 1024)[1]   # end of the first chunk
+    head = bytes(memoryview(data)[:first])
+    offs3 = chunk_offsets(head, 32 * 1024 * 1024)
+    nbytes = data.nbytes
+    del data
+    free0, _ = torch.cuda.mem_get_info()
+    with native.Counter(k, native.ALPHABET_NT2) as ctx:
+        st = native.count_file([ctx], path, 100 * 1024 * 1024, 10)
+        free1, _ = torch.cuda.mem_get_info()
+        stats = ctx.stats()
+        kmers, counts = ctx.export()
+    assert st["chunked"] == 1 and st["chunks"] == 78 and st["text_bytes"] == nbytes
+    assert stats["windows"] == reads * (150 - k + 1) and stats["exotic_windows"] == 0 and stats["mode_name"] == "hash128"
+    keys = kmers.view("S%d" % k).reshape(-1)
+    assert np.all(keys[:-1] < keys[1:]) and np.all(counts >= 10)
+    assert free0 - free1 < 6 * (1 << 30) < nbytes  # working set of a 100 MiB chunk, not of the 8 GB sample
+    os.unlink(path)
+    # linearity at c = 1 on the head
+    hpath = tmp_path / "S3_head.fna"
+    hpath.write_bytes(head)
+    with native.Counter(k, native.ALPHABET_NT2) as a, native.Counter(k, native.ALPHABET_NT2) as b:
+        sth = native.count_file([a], hpath, 32 * 1024 * 1024, 1)
+        assert sth["chunks"] == len(offs3) - 1 >= 3
+        for lo, hi in zip(offs3[:-1], offs3[1:]):
+            b.count_chunk(memoryview(head)[lo:hi], 1)
+        ka, ca = a.export()
+        kb, cb = b.export()
+        wa = a.stats()["windows"]
+    assert np.array_equal(ka, kb) and np.array_equal(ca, cb)
+    assert int(ca.sum()) == wa == head.count(b">") * (150 - k + 1)
+    akeys = ka.view("S%d" % k).reshape(-1)
+    assert np.all(akeys[:-1] < akeys[1:])
+    with native.Counter(k, native.ALPHABET_NT2) as c10:
+        native.count_file([c10], hpath, 32 * 1024 * 1024, 2)
+        k10, n10 = c10.export()
+    keys10 = k10.view("S%d" % k).reshape(-1)
+    pos = np.searchsorted(akeys, keys10)
+    assert np.all(pos < max(akeys.size, 1)) and np.array_equal(akeys[pos], keys10) and np.all(n10 <= ca[pos])
+
+
 def test_many_contexts_and_threads():
     """Contexts are independent: 6 of them counting different inputs from 6 host threads at once,
     then 150 create/count/destroy cycles (no leak, no cross-talk)."""
