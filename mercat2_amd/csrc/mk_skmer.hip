@@ -260,7 +260,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+#ifdef SK_ABL_NOCURSOR  // (timing ablation only: no reservation, runs land on top of each other)
+        r[i] = v[i] ? start[b] : 0ull;
+#else
         r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+#endif
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
@@ -293,7 +297,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
         const unsigned b = sk_bucket(mm, p1_log2);
         const unsigned base = gbase[b];
         const unsigned rank = atomicAdd(&lh[b], 1u);
+#ifdef SK_ABL_NOSTORE   // (timing ablation only: the record is built and dropped)
+        if (base != ~0u && rank == 0xFFFFFFFFu) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+#else
         if (base != ~0u) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+#endif
       });
     }
     __syncthreads();

@@ -46,19 +46,19 @@ def split_points(sorted_keys: torch.Tensor, key_bits: int, world: int) -> torch.
     return torch.cat([zero, cut, end])
 
 
-def exchange_rows(rows: torch.Tensor, key_bits: int, extra: int = 0, group=None) -> Tuple[torch.Tensor, List[int]]:
+def exchange_rows(rows: torch.Tensor, key_bits: int, extra: int = 0, group=None, always: bool = False) -> Tuple[torch.Tensor, List[int]]:
     """All-to-all of table rows by key range.  ``rows`` is (n, w) int64: the key's word(s) then the
     count, ascending by key (unsigned; rows[:, 0] is the most significant word and ``key_bits`` the bits
     it uses).  Returns (the rows this rank owns = what every peer sent, in peer order; every rank's
     ``extra``).  Two collectives: the row counts (with ``extra`` riding along) and the rows."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not always:  # (always: run the collectives even for one rank -- a test of the RCCL path on one GPU)
         return rows, [int(extra)]
     dev = rows.device
     if dev.type != "cpu" and dist.get_backend(group) == "gloo":
         # gloo moves host memory: stage through the CPU (test / single-GPU rehearsal path; with
         # backend "nccl" = RCCL the tensors stay on the device and travel over xGMI)
-        got, extras = exchange_rows(rows.cpu(), key_bits, extra, group)
+        got, extras = exchange_rows(rows.cpu(), key_bits, extra, group, always)
         return got.to(dev), extras
     pts = split_points(rows[:, 0], key_bits, world)
     send = (pts[1:] - pts[:-1]).to(torch.int64)
@@ -78,7 +78,7 @@ def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, grou
     return rows[:, 0].contiguous(), rows[:, 1].contiguous()
 
 
-def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0) -> int:
+def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0, always: bool = False) -> int:
     """Re-partition ctx's running table across the ranks of `group` by key range and sum.
     On return ctx holds exactly the packed rows of its own range; rows kept as text (characters
     outside the alphabet, k > 64: rare) all sit on rank 0.  With ``min_count`` > 1 rows whose merged
@@ -86,7 +86,7 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0)
     merge).  Returns the number of rows this rank now owns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and not always:
         if min_count > 1:
             ctx.filter_min(min_count)
         return ctx.rows()
@@ -102,7 +102,7 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0)
     rows = torch.cat([keys[:n], cnts[:n, None]], dim=1)
     ex_k, ex_c = ctx.export_exotic()
     ctx.reset()
-    got, extras = exchange_rows(rows, 64 if words == 2 else key_bits, int(ex_c.size), group)
+    got, extras = exchange_rows(rows, 64 if words == 2 else key_bits, int(ex_c.size), group, always)
     if got.shape[0]:
         rk = got[:, :words].contiguous()
         rc = got[:, words].contiguous()

@@ -201,3 +201,50 @@ def test_bench_launches_ranks_and_strong_rows_match(tmp_path):
     assert two["config"]["chunks"] >= 3
     assert two["rows"] == one["rows"] > 0
     assert two["also"]["scaling"] == "weak" and two["also"]["rows"] >= one["rows"]
+
+
+# ------------------------------------------------------------------------------- the RCCL backend itself
+_RCCL_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, os.environ["MK_ROOT"])
+import numpy as np, torch, torch.distributed as dist
+from mercat2_amd import native
+from mercat2_amd import dist as mkdist
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+assert dist.get_backend() == "nccl"
+ones = torch.ones(1, dtype=torch.int64, device=dev)
+dist.all_reduce(ones)
+assert int(ones.item()) == 1
+data = native.synth_reads(150_000, 31, 60_000, 150, 32).tobytes() + b">polyT\n" + b"T" * 100 + b"\n>odd\nACGTNNACGTRYACGTACGTACGTACGTACGTAACC\n"
+for k, c in ((31, 2), (32, 1), (63, 2), (5, 1)):
+    with native.Counter(k, native.ALPHABET_NT2, device=0) as ctx:
+        ctx.count_chunk(data, c)
+        want = ctx.export()
+        # the whole exchange -- export on the device, split points, the two all_to_all_single calls, import -- with
+        # the one rank sending everything to itself over RCCL
+        rows = mkdist.merge_ranks(ctx, 2 * k, device=dev, always=True)
+        got = ctx.export()
+    assert rows == want[1].size, (k, rows, want[1].size)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), k
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_rccl_backend_runs_the_exchange_on_one_rank(tmp_path):
+    """init_process_group("nccl", device_id=...) and the exchange's collectives (all_reduce, all_to_all_single with
+    split sizes on int64 (rows, words + 1) tensors) on RCCL itself -- one rank, which is all one GPU allows; the
+    2-rank tests above use gloo for the same logic."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "rccl_one.py"
+    script.write_text(_RCCL_SCRIPT)
+    env = dict(os.environ, MK_ROOT=str(ROOT), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, (p.stdout[-1000:], p.stderr[-3000:])

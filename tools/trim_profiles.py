@@ -14,7 +14,7 @@ for ctx in (2, 1):
         continue
     rows = list(csv.DictReader(open(files[0])))
     with open("profiles/%s_kernel_stats_ctx%d.csv" % (rnd, ctx), "w") as w:
-        w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --contexts %d\n" % ctx)
+        w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-file-leg --contexts %d\n" % ctx)
         w.write("# S2 workload (10M x 150bp, k=31, -c 10, 16 chunks); 4 passes incl. warmup; kernel names trimmed\n")
         w.write("name,calls,total_ms,avg_us,pct\n")
         for r in rows:
@@ -22,6 +22,19 @@ for ctx in (2, 1):
     line = [l for l in open("gpurun_out/prof_%s_ctx%d.log" % (tag, ctx)) if l.startswith('{"metric"')]
     if line:
         open("profiles/%s_bench_under_rocprof_ctx%d.json" % (rnd, ctx), "w").write(line[-1])
+
+files = glob.glob("gpurun_out/prof_%s_k63/*/*kernel_stats.csv" % tag)
+if files:
+    rows = list(csv.DictReader(open(files[0])))
+    with open("profiles/%s_kernel_stats_k63.csv" % rnd, "w") as w:
+        w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-file-leg --k 63 --reads 50000000 --genome 50000000 --genome-seed 6 --read-seed 7\n")
+        w.write("# S3 workload (50M x 150bp from a 50 Mbp genome, k=63, -c 10, 78 chunks; two-word keys); kernel names trimmed\n")
+        w.write("name,calls,total_ms,avg_us,pct\n")
+        for r in rows:
+            w.write("%s,%s,%.3f,%.1f,%s\n" % (short(r["Name"]), r["Calls"], int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    line = [l for l in open("gpurun_out/prof_%s_k63.log" % tag) if l.startswith('{"metric"')]
+    if line:
+        open("profiles/%s_bench_under_rocprof_k63.json" % rnd, "w").write(line[-1])
 
 pmc = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -38,7 +51,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 if pmc:
     out = {}
     with open("profiles/%s_pmc_traffic.csv" % rnd, "w") as w:
-        w.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --contexts 1\n")
+        w.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, kernel-trace only) -- python3 bench.py --steps 1 --warmup 1 --no-cpu --no-file-leg --contexts 1\n")
         w.write("# counters in KB per launch. hbm_bytes_per_launch applies the gfx950 correction of MI355X_MICROARCH.md (HBM section):\n")
         w.write("#   FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> doubled; WRITE_SIZE as read.\n")
         w.write("name,launches,fetch_kb,write_kb,hbm_bytes_per_launch,avg_us\n")
