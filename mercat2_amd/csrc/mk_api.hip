@@ -388,7 +388,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
   else if (partitioned) {
     // (the super-k-mer scatter keeps 32-bit record indices in LDS)
-    const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= 18 && c->k <= 32 && seq_len < 0xFFFFFF00ull;
+    const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= 18 && c->k <= 32 && seq_len < 0xFE000000ull;
     rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
   }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);

@@ -47,6 +47,7 @@
 #define SK_SCAT_SUBT 2
 #endif
 #define SK_MAX_P1 8192
+#define SK_NOFIT 0xFF000000u    // lh[] value of a (tile, bucket) run that does not fit its region: nothing is stored
 #ifndef SKC_SLOTS
 #define SKC_SLOTS 8192          // LDS table slots of one workgroup (12 bytes each)
 #endif
@@ -204,8 +205,10 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
                                                                    MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                    u64* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                                    int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
+  // lh[b]: pass 1 counts the tile's records of bucket b; after the reservation it holds the record index at which
+  // the tile's run in that bucket starts (the launcher keeps indices below SK_NOFIT) and pass 2's atomic add hands
+  // out base + rank in one step -- one array instead of two, which is what lets a tile park a second analysis
   __shared__ unsigned lh[SK_MAX_P1];
-  __shared__ unsigned gbase[SK_MAX_P1];  // record index of the tile's run in each bucket (the launcher keeps indices below 2^32)
   constexpr int PK = SK_SCAT_SUBT > 1 ? SK_SCAT_SUBT - 1 : 1;  // parked analyses (56 bytes per thread each)
   __shared__ uint2 pk_mask[PK][SK_SCAT_THREADS];
   __shared__ ulonglong2 pk_w[PK][SK_SCAT_THREADS];
@@ -262,6 +265,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
 #ifdef SK_ABL_NOCURSOR  // (timing ablation only: no reservation, runs land on top of each other)
         r[i] = v[i] ? start[b] : 0ull;
+#elif defined(SK_ABL_WGSCOPE)  // (timing ablation only: the add is performed in this XCD's L2 -- not coherent across XCDs)
+        r[i] = v[i] ? __hip_atomic_fetch_add(&cursor[b], (u64)v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
 #else
         r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
 #endif
@@ -273,8 +278,7 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
           // a run that would cross the end of its bucket's region (sampled sizes only) is not written
           const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
           spilled |= fits ? 0u : 1u;
-          gbase[b] = fits ? (unsigned)r[i] : ~0u;
-          lh[b] = 0;
+          lh[b] = fits ? (unsigned)r[i] : SK_NOFIT;
         }
       }
     }
@@ -295,12 +299,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
       (void)canon;
       sk_walk(runs, w0, w1, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
-        const unsigned base = gbase[b];
-        const unsigned rank = atomicAdd(&lh[b], 1u);
+        const unsigned at = atomicAdd(&lh[b], 1u);  // base + rank
 #ifdef SK_ABL_NOSTORE   // (timing ablation only: the record is built and dropped)
-        if (base != ~0u && rank == 0xFFFFFFFFu) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+        if (at == 0xFFFFFFFFu) part[(size_t)at] = sk_make_record(w0, w1, jstart, nk, k);
 #else
-        if (base != ~0u) part[(size_t)base + rank] = sk_make_record(w0, w1, jstart, nk, k);
+        if (at < SK_NOFIT) part[(size_t)at] = sk_make_record(w0, w1, jstart, nk, k);
 #endif
       });
     }
