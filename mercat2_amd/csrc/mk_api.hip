@@ -106,9 +106,30 @@ extern "C" const char* mk_last_error(const mk_ctx* c) { return c ? c->err.c_str(
 
 extern "C" int mk_words_per_key(const mk_ctx* c) { return c ? (c->mode == MK_MODE_HASH128 ? 2 : 1) : 0; }
 
+// Row totals of the last merge that were read back without waiting (process_chunk_fast): add them up. Only call
+// when the stream is known to have passed that copy.
+static void fold_pending(mk_ctx* c) {
+  if (!c->pending_rows) return;
+  const MkChunkInfo* p = c->h_info + 1;
+  if (c->mode == MK_MODE_HASH128) c->run128_rows += (size_t)p->new_rows;
+  else c->run_rows += (size_t)p->new_rows;
+  c->run_ref_rows += (size_t)p->new_rows_ref;
+  c->pending_rows = false;
+}
+
 static int pull_info(mk_ctx* c) {
   MK_HIP(hipMemcpyAsync(c->h_info, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
   MK_HIP(hipStreamSynchronize(c->stream));
+  fold_pending(c);  // (the stream is idle: whatever was in flight has landed)
+  return MK_OK;
+}
+
+// Before anything reads run_rows & co.
+static int settle(mk_ctx* c) {
+  if (!c->pending_rows) return MK_OK;
+  MK_HIP(hipSetDevice(c->device));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  fold_pending(c);
   return MK_OK;
 }
 
@@ -152,7 +173,8 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   if ((e = hipSetDevice(device)) != hipSuccess) return fail(MK_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-  if ((e = hipHostMalloc((void**)&c->h_info, sizeof(MkChunkInfo), hipHostMallocDefault)) != hipSuccess)
+  c->use_speculation = getenv("MK_NO_SPECULATION") ? 0 : 1;
+  if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo), hipHostMallocDefault)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((rc = mk_buf_reserve(c, c->info, sizeof(MkChunkInfo) + 64)) != MK_OK) return fail(rc, c->err);
   if (c->mode == MK_MODE_DENSE) {
@@ -187,6 +209,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
 extern "C" int mk_reset(mk_ctx* c) {
   if (!c) return MK_ERR_ARG;
   MK_HIP(hipSetDevice(c->device));
+  if (c->pending_rows) { MK_HIP(hipStreamSynchronize(c->stream)); c->pending_rows = false; }
   if (c->mode == MK_MODE_DENSE) {
     MK_HIP(hipMemsetAsync(c->run.p, 0, c->run_slots * sizeof(u64), c->stream));
   } else if (c->run_slots) {
@@ -210,6 +233,7 @@ extern "C" int mk_reset(mk_ctx* c) {
 
 extern "C" int mk_set_canonical(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_canonical: only the nucleotide alphabet has a reverse complement"; return MK_ERR_ARG; }
   if (on && c->mode != MK_MODE_DENSE && c->mode != MK_MODE_HASH64) { c->err = "mk_set_canonical: canonical counting is implemented for k <= 32"; return MK_ERR_ARG; }
   if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->st.chunks) {
@@ -321,10 +345,113 @@ static int grow_run_ref(mk_ctx* c, size_t need_rows) {
 }
 
 // --------------------------------------------------------------------------- the pipeline
+#define MK_RETRY_GENERAL 1  // (internal) the speculative lane met input it does not handle: take the general path
+
+// The partitioned nucleotide paths (one-word keys 18 <= k <= 32, two-word keys 33 <= k <= 64) with ONE host
+// read-back per chunk instead of three.  Everything up to the count kernel is launched on the assumption that the
+// fast parser will do (no blank inside a sequence line) and with buffers and grids sized from the raw length (the
+// kernels read the true seq_len on the device); the one read-back after the count kernel tells whether that held
+// (otherwise MK_RETRY_GENERAL), whether symbols outside the alphabet need the by-reference kernel (then it runs
+// now: one more read-back, rare), and how many rows survive; the merge is launched and its row totals are copied
+// back without waiting -- they are added up when the next read-back (or settle()) has passed them.
+static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
+  int rc;
+  const size_t begin = (size_t)((uintptr_t)d_raw & 15);
+  const uint8_t* d_al = d_raw - begin;
+  MK_HIP(hipSetDevice(c->device));
+  MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if ((rc = mk_buf_reserve(c, c->seq, n + 256)) != MK_OK) return rc;
+  const size_t bad_words = n / 64 + 4;
+  if ((rc = mk_buf_reserve(c, c->bad, (bad_words + 2) * 8)) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->codes, (2 * bad_words + 8) * 8)) != MK_OK) return rc;
+  if ((rc = mk_launch_fparse(c, d_al, begin, n, /*fuse_pack_nt=*/true)) != MK_OK) return rc;
+  const bool two = c->mode == MK_MODE_HASH128;
+  c->rtab_chunk_slots = 0;
+  c->surv_regions = 0;
+  c->ctab_slots = 0;
+  rc = two ? mk_launch_count_superkmer2(c, n, min_count) : mk_launch_count_superkmer(c, n, min_count);  // (seq_len <= n)
+  if (rc) return rc;
+  if ((rc = pull_info(c)) != MK_OK) return rc;  // the one read-back
+  MkChunkInfo* h = c->h_info;
+  if (h->parse_fallback) return MK_RETRY_GENERAL;
+  if (h->non_ascii) {
+    c->err = "input holds " + std::to_string(h->non_ascii) +
+             " sequence byte(s) >= 0x80 (non-ASCII sequence text is not supported; the chunk was not counted)";
+    return MK_ERR_NON_ASCII;
+  }
+  const size_t seq_len = (size_t)h->seq_len;
+  if (h->bad_symbols) {  // windows holding a symbol outside the alphabet: by reference, now
+    const u64 bound = std::min<u64>((u64)seq_len, h->bad_symbols * (u64)c->k);
+    c->rtab_chunk_slots = pow2_at_least(2 * (size_t)bound);
+    if ((rc = mk_buf_reserve(c, c->rtab_chunk, c->rtab_chunk_slots * sizeof(MkSlot))) != MK_OK) return rc;
+    if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->rtab_chunk.p, c->rtab_chunk_slots)) != MK_OK) return rc;
+    if ((rc = mk_launch_count_byref(c, seq_len, true)) != MK_OK) return rc;
+    if ((rc = mk_launch_count_survivors(c, min_count)) != MK_OK) return rc;
+    if ((rc = pull_info(c)) != MK_OK) return rc;
+  }
+  if (h->part_overflow) {  // (see process_chunk: partition again from the exact histogram)
+    if (!c->part_sampled) { c->err = "partition overflow without sampling (internal error)"; return MK_ERR_STATE; }
+    if (getenv("MK_VERBOSE")) fprintf(stderr, "[mk] sampled partition too small (where=%llu): exact pass\n", h->part_overflow);
+    h->windows = h->records = h->distinct = h->survivors = h->side = h->errors = h->part_overflow = 0;
+    MK_HIP(hipMemcpyAsync(c->info.p, h, sizeof(MkChunkInfo), hipMemcpyHostToDevice, c->stream));
+    c->st.part_retries += 1;
+    rc = two ? mk_launch_count_superkmer2(c, seq_len, min_count, /*exact=*/true) : mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true);
+    if (rc) return rc;
+    if ((rc = pull_info(c)) != MK_OK) return rc;
+  }
+  if (h->errors) {
+    c->err = "counting kernel reported " + std::to_string(h->errors) + " unrecoverable condition(s) (bucket too large to split)";
+    return MK_ERR_RANGE;
+  }
+  if (!two && h->survivors && (rc = grow_run64(c, c->run_rows + (size_t)h->survivors)) != MK_OK) return rc;
+  if (h->survivors_ref && (rc = grow_run_ref(c, c->run_ref_rows + (size_t)h->survivors_ref)) != MK_OK) return rc;
+  if (two && (h->survivors || h->survivors_ref) &&
+      (rc = grow_run128(c, c->run128_rows + (size_t)h->survivors + (size_t)h->survivors_ref)) != MK_OK) return rc;
+  if (h->survivors && seq_len) {
+    const size_t p1 = (size_t)1 << c->p1_log2;
+    const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
+    mk_prof_begin(c, MK_K_FILTER);
+    rc = two ? mk_launch_import128_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_keys2.p,
+                                           (const uint64_t*)c->surv_cnts.p, meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1)
+             : mk_launch_import_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p,
+                                        meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+    mk_prof_end(c);
+    if (rc) return rc;
+  }
+  if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;  // (survivors of the by-reference chunk table, if any)
+  // the merge's row totals: copied back, not waited for
+  MK_HIP(hipMemcpyAsync(c->h_info + 1, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
+  c->pending_rows = true;
+  if (h->side && h->side >= min_count) c->run_side += h->side;
+  if (h->distinct) c->dup_hint = (double)h->windows / (double)h->distinct;
+  if (h->records) c->nk_hint = (double)(h->windows + h->exotic) / (double)h->records;
+  if (getenv("MK_VERBOSE"))
+    fprintf(stderr, "[mk] chunk (one read-back): raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu p1=2^%d dup=%.2f nk=%.2f\n",
+            n, seq_len, (unsigned long long)h->windows, (unsigned long long)h->records, (unsigned long long)h->distinct,
+            (unsigned long long)h->survivors, c->p1_log2, c->dup_hint, c->nk_hint);
+  c->st.table_slots = c->rtab_chunk_slots;
+  c->st.raw_bytes += n;
+  c->st.symbols += h->symbols;
+  c->st.windows += h->windows + h->exotic;
+  c->st.exotic_windows += h->exotic;
+  c->st.chunks += 1;
+  c->st.records += h->records;
+  c->st.distinct += h->distinct;
+  c->st.survivors += h->survivors + h->survivors_ref + ((h->side && h->side >= min_count) ? 1 : 0);
+  return MK_OK;
+}
+
 // d_raw may be unaligned: the fast parser reads from the 16-byte boundary below it and ignores the
 // bytes in front; only the (rare) general-parser fallback needs an aligned copy.
 static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
   int rc;
+  if (c->use_speculation && c->use_fast_parse && c->alphabet == MK_ALPHABET_NT2 && n && n < 0xFE000000ull &&
+      ((c->mode == MK_MODE_HASH64 && c->use_partition && c->use_superkmer && c->k >= 18 && c->k <= 32) ||
+       (c->mode == MK_MODE_HASH128 && c->use_superkmer2))) {
+    rc = process_chunk_fast(c, d_raw, n, min_count);
+    if (rc != MK_RETRY_GENERAL) return rc;
+  }
+  if ((rc = settle(c)) != MK_OK) return rc;
   const size_t begin = (size_t)((uintptr_t)d_raw & 15);
   const uint8_t* d_al = d_raw - begin;
   MK_HIP(hipSetDevice(c->device));
@@ -704,6 +831,7 @@ static void merged_rows(const mk_ctx* c, const ExportView& v, F&& f) {
 
 static int build_view(mk_ctx* c, ExportView& v) {
   MK_HIP(hipSetDevice(c->device));
+  { int rc_ = settle(c); if (rc_) return rc_; }
   int rc = gather_packed(c, v, nullptr, nullptr, 0, nullptr, true);
   if (rc) return rc;
   return gather_ref(c, v, true);
@@ -711,6 +839,7 @@ static int build_view(mk_ctx* c, ExportView& v) {
 
 extern "C" int mk_export_size(mk_ctx* c, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (c->mode == MK_MODE_DENSE) {
     ExportView v;
     MK_HIP(hipSetDevice(c->device));
@@ -1022,6 +1151,7 @@ extern "C" int mk_alpha_stats(mk_ctx* c, mk_alpha_t* out) {
 // buffers come back on the next chunk.
 extern "C" int mk_trim(mk_ctx* c) {
   if (!c) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (c->in_chunk) { c->err = "mk_trim: a chunk is open"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(c->device));
   MK_HIP(hipStreamSynchronize(c->stream));
@@ -1038,6 +1168,7 @@ extern "C" int mk_trim(mk_ctx* c) {
 // ------------------------------------------------------------------- multi-GPU plumbing
 extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_counts, size_t cap, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (c->mode == MK_MODE_BYREF) { *rows = 0; return MK_OK; }  // rows travel as text (mk_export_exotic)
   MK_HIP(hipSetDevice(c->device));
   ExportView v;
@@ -1047,6 +1178,7 @@ extern "C" int mk_export_pairs_device(mk_ctx* c, uint64_t* d_keys, uint64_t* d_c
 extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
   if (!c) return MK_ERR_ARG;
   if (!rows) return MK_OK;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (c->mode == MK_MODE_BYREF) { c->err = "mk_import_pairs_device: context has no packed table"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(c->device));
   int rc;
@@ -1070,6 +1202,7 @@ extern "C" int mk_import_pairs_device(mk_ctx* c, const uint64_t* d_keys, const u
 extern "C" int mk_export_exotic(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t cap, size_t* rows) {
   if (!c || !rows) return MK_ERR_ARG;
   MK_HIP(hipSetDevice(c->device));
+  { int rc_ = settle(c); if (rc_) return rc_; }
   ExportView v;
   int rc = gather_ref(c, v, true);
   if (rc) return rc;
@@ -1089,6 +1222,7 @@ extern "C" int mk_import_exotic(mk_ctx* c, const uint8_t* kmers, const uint64_t*
   if (!rows) return MK_OK;
   if (!kmers || !counts) return MK_ERR_ARG;
   MK_HIP(hipSetDevice(c->device));
+  { int rc_ = settle(c); if (rc_) return rc_; }
   int rc;
   const size_t k = (size_t)c->k;
   if ((rc = mk_buf_reserve(c, c->ex_keys2, rows * k + 64)) != MK_OK) return rc;
@@ -1108,6 +1242,7 @@ extern "C" int mk_import_exotic(mk_ctx* c, const uint8_t* kmers, const uint64_t*
 // (lib/mercat2_kmers.py:73-76 applies it once per file).
 extern "C" int mk_filter_min(mk_ctx* c, uint64_t min_count) {
   if (!c) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   if (c->in_chunk) { c->err = "mk_filter_min: a chunk is open"; return MK_ERR_STATE; }
   if (min_count <= 1) return MK_OK;
   MK_HIP(hipSetDevice(c->device));
@@ -1205,6 +1340,7 @@ extern "C" int mk_set_profiling(mk_ctx* c, int on) {
 
 extern "C" int mk_get_stats(mk_ctx* c, mk_stats_t* out) {
   if (!c || !out) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
   (void)hipSetDevice(c->device);
   prof_collect(c);
   c->st.mode = c->mode;

@@ -113,7 +113,10 @@ struct mk_ctx {
   MkDevBuf seq, codes, bad;
   MkDevBuf tile_maps;   // parse scratch
   MkDevBuf info;        // MkChunkInfo on device
-  MkChunkInfo* h_info = nullptr;  // pinned host copy
+  MkChunkInfo* h_info = nullptr;  // pinned host copy (two structs: [1] receives the read-back that is not waited for)
+  bool pending_rows = false;      // h_info[1] holds (or will hold, once the stream has passed the copy) the row totals
+                                  // of the last chunk's merge, not yet added to run_rows / run128_rows / run_ref_rows
+  int use_speculation = 1;        // one read-back per chunk on the partitioned paths (mk_api.hip: process_chunk_fast)
 
   // chunk tables
   MkDevBuf ctab;        // MkSlot[] (hash64) / MkSlot128[] (hash128) / u64 bins (dense)
