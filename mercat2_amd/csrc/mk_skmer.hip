@@ -516,6 +516,8 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               u64 kk[SKC_B], cur[SKC_B];
               unsigned hh[SKC_B];
               unsigned live = 0;  // bit u: slot u holds a key of this pass
+              // every key's compare-and-swap is issued as soon as its slot is known, so that the hashing of the
+              // later keys runs while the earlier ones are on their way through the LDS
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u) {
                 kk[u] = mk_canon2(x >> kshift, k, CANON);
@@ -527,16 +529,13 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                   side_pass += side_done ? 0 : 1;
                   on = false;
                 }
+                if (s && ((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) on = false;
                 live |= on ? (1u << u) : 0u;
+                if (on) cur[u] = atomicCAS(&tkey[skc_home(hh[u])], MK_EMPTY, kk[u]);
+#ifdef SKC_SCHED_FENCE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
               }
-              if (s) {
-#pragma unroll
-                for (int u = 0; u < SKC_B; ++u)
-                  if (((hh[u] & ((1u << SKC_SUB_BITS) - 1)) >> sel_shift) != idx) live &= ~(1u << u);
-              }
-#pragma unroll
-              for (int u = 0; u < SKC_B; ++u)
-                if ((live >> u) & 1u) cur[u] = atomicCAS(&tkey[skc_home(hh[u])], MK_EMPTY, kk[u]);
               unsigned fail = 0;
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u)
