@@ -117,12 +117,24 @@ __device__ __forceinline__ unsigned wave_step(unsigned nl, unsigned gt, unsigned
   return __shfl(hout, 63);
 }
 
+// zero_codes / zero_bad (fused nucleotide pack only): the emit pass ORs partial words in, so the packed words and the
+// bad bitmap must start from zero.  This pass is over before the emit pass starts, so every wave clears the slice
+// that corresponds to its input bytes (two memset launches of 39 MB per 100 MiB chunk less); the last wave takes
+// the padding words as well.
 __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __restrict__ raw, size_t begin, size_t n, size_t nwaves,
-                                                             FpEntry* __restrict__ entries, MkChunkInfo* __restrict__ info) {
+                                                             FpEntry* __restrict__ entries, MkChunkInfo* __restrict__ info,
+                                                             u64* __restrict__ zero_codes, u64* __restrict__ zero_bad,
+                                                             size_t code_words, size_t bad_words) {
   const size_t wave = (size_t)blockIdx.x * FP_WAVES + (threadIdx.x >> 6);
   if (wave >= nwaves) return;
   const int lane = threadIdx.x & 63;
   const size_t base = wave * FP_WAVE_BYTES;
+  if (zero_codes) {
+    constexpr size_t CW = FP_WAVE_BYTES / 32, BW = FP_WAVE_BYTES / 64;  // words of this wave's slice
+    const size_t c_end = wave + 1 == nwaves ? code_words : (wave + 1) * CW, b_end = wave + 1 == nwaves ? bad_words : (wave + 1) * BW;
+    for (size_t w = wave * CW + (size_t)lane; w < c_end && w < code_words; w += 64) zero_codes[w] = 0ull;
+    for (size_t w = wave * BW + (size_t)lane; w < b_end && w < bad_words; w += 64) zero_bad[w] = 0ull;
+  }
   unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
   unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0;
 #pragma unroll 1
@@ -404,8 +416,8 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, 
   const size_t n = begin + len;
   u64* codes = fuse_pack_nt ? (u64*)c->codes.p : nullptr;
   u64* bad = fuse_pack_nt ? (u64*)c->bad.p : nullptr;
-  if (fuse_pack_nt) {  // partial words are OR-ed in: start from zero (padding words included)
-    const size_t bad_words = n / 64 + 4;
+  const size_t bad_words = n / 64 + 4;  // partial words are OR-ed in: they start from zero (padding words included)
+  if (fuse_pack_nt && len == 0) {
     MK_HIP(hipMemsetAsync(c->codes.p, 0, 2 * bad_words * sizeof(u64), c->stream));
     MK_HIP(hipMemsetAsync(c->bad.p, 0, bad_words * sizeof(u64), c->stream));
     if (n == 0) MK_HIP(hipMemsetAsync(c->bad.p, 0xFF, 4 * sizeof(u64), c->stream));
@@ -420,7 +432,8 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, 
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const unsigned blocks = (unsigned)((nwaves + FP_WAVES - 1) / FP_WAVES);
   mk_prof_begin(c, MK_K_PARSE);
-  hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, entries, info);
+  hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, entries, info, codes, bad,
+                     2 * bad_words, bad_words);  // (the summary pass clears the packed words and the bad bitmap)
   hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info);
   hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, scan,
                      (uint8_t*)c->seq.p, info, codes, bad);

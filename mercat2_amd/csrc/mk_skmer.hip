@@ -125,10 +125,9 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
   __syncthreads();
   for (unsigned b = threadIdx.x; b < p1; b += blockDim.x) {
     const unsigned v = lh[b];
-    if (v) {
-      atomicAdd(&hist[b], (u64)v);
-      atomicAdd(&khist[b], (u64)lk[b]);
-    }
+    // one global add per bucket: records in the low word, k-mers in the high word (a chunk holds fewer than 2^32
+    // symbols, so neither half can carry) -- the per-workgroup flush is most of this kernel's HBM traffic
+    if (v) atomicAdd(&hist[b], (u64)v | ((u64)lk[b] << 32));
   }
 }
 
@@ -163,8 +162,9 @@ __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ his
   for (int q = 0; q < PER; ++q) {
     const unsigned i = lo + q;
     const bool on = (unsigned)q < per && i < p1;
-    cap[q] = on ? sk_cap(hist[i], sample_log2, SK_R / SK_NKMAX, sigmas) : 0;
-    kcap[q] = on ? (sk_cap(khist[i], sample_log2, SK_R, sigmas) + div - 1) / div : 0;
+    const u64 hk = on ? hist[i] : 0ull;  // records | k-mers << 32 (see the histogram kernels' flush)
+    cap[q] = on ? sk_cap(hk & 0xFFFFFFFFull, sample_log2, SK_R / SK_NKMAX, sigmas) : 0;
+    kcap[q] = on ? (sk_cap(hk >> 32, sample_log2, SK_R, sigmas) + div - 1) / div : 0;
     acc += cap[q];
     kacc += kcap[q];
   }

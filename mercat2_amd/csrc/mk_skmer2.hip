@@ -118,10 +118,9 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
   __syncthreads();
   for (unsigned b = threadIdx.x; b < p1; b += blockDim.x) {
     const unsigned v = lh[b];
-    if (v) {
-      atomicAdd(&hist[b], (u64)v);
-      atomicAdd(&khist[b], (u64)lk[b]);
-    }
+    // one global add per bucket: records in the low word, k-mers in the high word (a chunk holds fewer than 2^32
+    // symbols, so neither half can carry) -- the per-workgroup flush is most of this kernel's HBM traffic
+    if (v) atomicAdd(&hist[b], (u64)v | ((u64)lk[b] << 32));
   }
 }
 
