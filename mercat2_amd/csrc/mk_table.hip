@@ -115,7 +115,9 @@ __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __r
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
                              const uint64_t* nsurv, size_t p1) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
-  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
+  // (few workgroups, each wave walking several buckets: every workgroup ends with one add to the same counter, and
+  // adds to one address are serialised by the L2 at ~4 ns each)
+  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, 512)), dim3(256), 0, c->stream, (const u64*)d_keys,
                      (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
                      (u64)(c->run_slots - 1), &info->new_rows);
   MK_HIP(hipGetLastError());
@@ -180,7 +182,7 @@ __global__ void mk_import128_regions_k(const u64* __restrict__ hi, const u64* __
 int mk_launch_import128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, const uint64_t* kstart,
                                 const uint64_t* nsurv, size_t p1) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
-  hipLaunchKernelGGL(mk_import128_regions_k, dim3(grid_for(p1 * 64, 256, 8192)), dim3(256), 0, c->stream, (const u64*)hi,
+  hipLaunchKernelGGL(mk_import128_regions_k, dim3(grid_for(p1 * 64, 256, 512)), dim3(256), 0, c->stream, (const u64*)hi,
                      (const u64*)lo, (const u64*)cnts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot128*)c->run128.p,
                      (u64)(c->run128_slots - 1), &info->new_rows);
   MK_HIP(hipGetLastError());
