@@ -349,7 +349,10 @@ __device__ __forceinline__ unsigned skc_step(unsigned slot, unsigned d) {
 
 #define SKC_B 8          // k-mers of a record expanded and probed together
 #define SKC_WAVES (SKC_THREADS / 64)
-#define SKC_QCAP 320     // deferred keys a wave can hold: < 64 left over + 4 slots x 64 lanes pushed at once
+#ifndef SKC_PUSH
+#define SKC_PUSH 4       // slots whose deferred keys are pushed before the stack is looked at again
+#endif
+#define SKC_QCAP (64 + 64 * SKC_PUSH)  // deferred keys a wave can hold: < 64 left over + SKC_PUSH slots x 64 lanes
 
 __device__ __forceinline__ unsigned skc_lane_rank(u64 mask) {  // set bits of mask below this lane
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -546,9 +549,9 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               // deferred keys -> the wave's stack (positions from ballots: no atomic), four slots at a time
               // so that the stack never holds more than SKC_QCAP; full groups of 64 are probed right away
 #pragma unroll
-              for (int half = 0; half < SKC_B; half += 4) {
+              for (int half = 0; half < SKC_B; half += SKC_PUSH) {
 #pragma unroll
-                for (int u = half; u < half + 4; ++u) {
+                for (int u = half; u < half + SKC_PUSH; ++u) {
                   const bool f = (fail >> u) & 1u;
                   const u64 m = __ballot(f);
                   if (m) {

@@ -1,6 +1,6 @@
 """Turn the rocprofv3 outputs of tools/make_profiles.sh (gpurun_out/) into the small committed
 summaries under profiles/."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 rnd = sys.argv[2] if len(sys.argv) > 2 else "round1"
 
@@ -9,10 +9,10 @@ def short(name):
     return m.group(1) if m else name[:40]
 
 for ctx in (2, 1):
-    files = glob.glob("gpurun_out/prof_%s_ctx%d/*/*kernel_stats.csv" % (tag, ctx))
+    files = sorted(glob.glob("gpurun_out/prof_%s_ctx%d/*/*kernel_stats.csv" % (tag, ctx)), key=os.path.getmtime)
     if not files:
         continue
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(files[-1])))  # (the newest run)
     with open("profiles/%s_kernel_stats_ctx%d.csv" % (rnd, ctx), "w") as w:
         w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu --no-file-leg --contexts %d\n" % ctx)
         w.write("# S2 workload (10M x 150bp, k=31, -c 10, 16 chunks); 4 passes incl. warmup; kernel names trimmed\n")
@@ -23,9 +23,9 @@ for ctx in (2, 1):
     if line:
         open("profiles/%s_bench_under_rocprof_ctx%d.json" % (rnd, ctx), "w").write(line[-1])
 
-files = glob.glob("gpurun_out/prof_%s_k63/*/*kernel_stats.csv" % tag)
+files = sorted(glob.glob("gpurun_out/prof_%s_k63/*/*kernel_stats.csv" % tag), key=os.path.getmtime)
 if files:
-    rows = list(csv.DictReader(open(files[0])))
+    rows = list(csv.DictReader(open(files[-1])))
     with open("profiles/%s_kernel_stats_k63.csv" % rnd, "w") as w:
         w.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu --no-file-leg --k 63 --reads 50000000 --genome 50000000 --genome-seed 6 --read-seed 7\n")
         w.write("# S3 workload (50M x 150bp from a 50 Mbp genome, k=63, -c 10, 78 chunks; two-word keys); kernel names trimmed\n")
@@ -38,11 +38,11 @@ if files:
 
 pmc = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    files = glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c))
+    files = sorted(glob.glob("gpurun_out/pmc_%s_%s/*/*counter_collection.csv" % (tag, c)), key=os.path.getmtime)
     if not files:
         continue
     agg = collections.defaultdict(lambda: [0, 0.0, 0])
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(files[-1])):
         a = agg[short(r["Kernel_Name"])]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
