@@ -214,8 +214,9 @@ __device__ __forceinline__ unsigned sk2c_lane_rank(u64 mask) {  // set bits of m
 }
 
 // Insert one 128-bit key, probing from its home slot (see the protocol in the header).  The lane that wins a slot
-// writes the key and publishes inside the loop iteration in which it won.
-__device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
+// writes the key and publishes inside the loop iteration in which it won.  tkey holds {hi, lo} side by side: one
+// 16-byte LDS access per key.
+__device__ __forceinline__ void sk2c_insert(ulonglong2* tkey, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
   unsigned slot = sk2c_home(h);
   bool done = false;
 #pragma unroll 1
@@ -224,8 +225,7 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
     if (c == 0) {
       c = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
       if (c == 0) {  // ours: write the key, then publish with count 1
-        thi[slot] = hi;
-        tlo[slot] = lo;
+        tkey[slot] = make_ulonglong2(hi, lo);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
         done = true;
@@ -233,7 +233,8 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
     }
     if (!done && !(c & SK2C_LOCK)) {  // (a slot that is being written is looked at again)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      if (thi[slot] == hi && tlo[slot] == lo) {
+      const ulonglong2 o = tkey[slot];
+      if (o.x == hi && o.y == lo) {
         atomicAdd(&tcnt[slot], 1u);
         done = true;
       } else {
@@ -246,13 +247,13 @@ __device__ __forceinline__ void sk2c_insert(u64* thi, u64* tlo, unsigned* tcnt, 
 }
 
 // The top n (<= 64) deferred keys of this wave's stack, one per lane, through the general insert.
-__device__ __forceinline__ void sk2c_drain(u64* thi, u64* tlo, unsigned* tcnt, const ulonglong2* q, unsigned& qcount, unsigned n,
+__device__ __forceinline__ void sk2c_drain(ulonglong2* tkey, unsigned* tcnt, const ulonglong2* q, unsigned& qcount, unsigned n,
                                            unsigned* ovf) {
   const unsigned lane = threadIdx.x & 63;
   qcount -= n;
   if (lane < n) {
     const ulonglong2 key = q[qcount + lane];
-    sk2c_insert(thi, tlo, tcnt, ovf, key.x, key.y, sk2c_hash(key.x, key.y));
+    sk2c_insert(tkey, tcnt, ovf, key.x, key.y, sk2c_hash(key.x, key.y));
   }
 }
 
@@ -263,9 +264,8 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
                                                                u64* __restrict__ out_cnt, int k, unsigned p1,
                                                                double dup_hint, double nk_hint) {
-  __shared__ u64 thi[SK2C_SLOTS];
-  __shared__ u64 tlo[SK2C_SLOTS];
-  __shared__ unsigned tcnt[SK2C_SLOTS];
+  __shared__ __attribute__((aligned(16))) ulonglong2 tkey[SK2C_SLOTS];  // {hi, lo}
+  __shared__ unsigned tcnt[SK2C_SLOTS];                                   // 0 free, LOCK being written, else the count
   __shared__ __attribute__((aligned(16))) ulonglong2 wq[SK2C_WAVES][SK2C_QCAP];  // deferred keys, one stack per wave
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
@@ -333,41 +333,36 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
               alive |= mine ? (1u << u) : 0u;
             }
           }
-          // batched first probe: states of the 8 home slots, claims of the free ones, then the key compares of the
-          // occupied ones.  Whatever does not settle at its home slot (another key there, a slot mid-write, a lost
-          // claim) is DEFERRED onto the wave's stack and probed 64 keys at a time, every lane busy.
+          // batched first probe, compare-and-swap first: a free home slot (most keys of a read set at 33 <= k <= 64 are
+          // new) is claimed by the very first LDS operation, the key goes in with one 16-byte write and the count is
+          // published; a slot that holds a count has its key read (one 16-byte read) and compared.  Whatever does not
+          // settle at its home slot (another key there, or a slot mid-write) is DEFERRED onto the wave's stack and
+          // probed 64 keys at a time, every lane busy.
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u)
-            st[u] = ((alive >> u) & 1u) ? __hip_atomic_load(&tcnt[sk2c_home(hh[u])], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+            st[u] = ((alive >> u) & 1u) ? atomicCAS(&tcnt[sk2c_home(hh[u])], 0u, SK2C_LOCK) : 0u;
           unsigned defer = 0;
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (((alive >> u) & 1u) && st[u] == 0) {
               const unsigned slot = sk2c_home(hh[u]);
-              st[u] = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
-              if (st[u] == 0) {
-                thi[slot] = khi[u];
-                tlo[slot] = klo[u];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
-              } else {
-                defer |= 1u << u;  // somebody else took the slot meanwhile
-              }
+              tkey[slot] = make_ulonglong2(khi[u], klo[u]);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+              atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
               alive &= ~(1u << u);
             }
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-          u64 oh[SK2_NKMAX], ol[SK2_NKMAX];
+          ulonglong2 ok[SK2_NKMAX];
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             const bool look = ((alive >> u) & 1u) && !(st[u] & SK2C_LOCK);
-            oh[u] = look ? thi[sk2c_home(hh[u])] : 0ull;
-            ol[u] = look ? tlo[sk2c_home(hh[u])] : 0ull;
+            ok[u] = look ? tkey[sk2c_home(hh[u])] : make_ulonglong2(0ull, 0ull);
           }
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) {
             if (!((alive >> u) & 1u)) continue;
-            if (!(st[u] & SK2C_LOCK) && oh[u] == khi[u] && ol[u] == klo[u]) atomicAdd(&tcnt[sk2c_home(hh[u])], 1u);
+            if (!(st[u] & SK2C_LOCK) && ok[u].x == khi[u] && ok[u].y == klo[u]) atomicAdd(&tcnt[sk2c_home(hh[u])], 1u);
             else defer |= 1u << u;
           }
 #pragma unroll
@@ -378,26 +373,24 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
               if (f) myq[qcount + sk2c_lane_rank(m)] = make_ulonglong2(khi[u], klo[u]);
               qcount += (unsigned)__popcll(m);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              if (qcount >= 64) sk2c_drain(thi, tlo, tcnt, myq, qcount, 64u, ovf);
+              if (qcount >= 64) sk2c_drain(tkey, tcnt, myq, qcount, 64u, ovf);
             }
           }
           if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
-        if (qcount) sk2c_drain(thi, tlo, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
+        if (qcount) sk2c_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
         __syncthreads();  // A
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
         {
+          // the sweep reads the counts only; a slot's key only when its count reaches min_count
           constexpr int PER = SK2C_SLOTS / SK2C_THREADS;
-          u64 eh[PER], el[PER];
           unsigned ec[PER];
           unsigned mine = 0, occ = 0;
 #pragma unroll
           for (int q = 0; q < PER; ++q) {
             const unsigned i = q * SK2C_THREADS + threadIdx.x;
             ec[q] = tcnt[i];
-            eh[q] = thi[i];
-            el[q] = tlo[i];
             tcnt[i] = 0;
             occ += ec[q] != 0;
             if (over || (u64)ec[q] < min_count) ec[q] = 0;
@@ -415,8 +408,9 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
               if (mine && ec[q]) {
-                my_hi[at + o] = eh[q];
-                my_lo[at + o] = el[q];
+                const ulonglong2 key = tkey[q * SK2C_THREADS + threadIdx.x];
+                my_hi[at + o] = key.x;
+                my_lo[at + o] = key.y;
                 my_cnt[at + o] = ec[q];
                 ++o;
               }
