@@ -46,7 +46,13 @@
 #ifndef SK_SCAT_SUBT
 #define SK_SCAT_SUBT 2
 #endif
-#define SK_MAX_P1 8192
+#ifndef SK_MAX_P1_LOG2
+#define SK_MAX_P1_LOG2 13
+#endif
+#define SK_MAX_P1 (1 << SK_MAX_P1_LOG2)
+#ifndef SK_BUCKET_SYMS
+#define SK_BUCKET_SYMS 8192     // symbols of the chunk per bucket the bucket count aims at (~1.2K records, ~10K windows)
+#endif
 #define SK_NOFIT 0xFF000000u    // lh[] value of a (tile, bucket) run that does not fit its region: nothing is stored
 #ifndef SKC_SLOTS
 #define SKC_SLOTS 8192          // LDS table slots of one workgroup (12 bytes each)
@@ -66,7 +72,9 @@
 #ifndef SKC_CAS_FIRST
 #define SKC_CAS_FIRST 1  // claim-or-compare with ONE compare-and-swap per key instead of read + conditional swap: the insert is bound by LDS instruction issue, not by active lanes (count kernel -5 %)
 #endif
+#ifndef SKC_PRE
 #define SKC_PRE (2048 / SKC_THREADS)   // record batches (one record per thread each) per load round
+#endif
 #define SKC_LOADCAP (SKC_SLOTS / 2)
 #define SKC_TARGET (SKC_SLOTS * SKC_TARGET_PCT / 100)
 #define SKC_SUB_BITS 16
@@ -730,8 +738,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   const int k = c->k;
   // ~1.2K records (~10K windows) per bucket, between 256 and SK_MAX_P1 buckets
   int p1_log2 = 8;
-  while (p1_log2 < 13 && (seq_len >> p1_log2) > 8192) ++p1_log2;
-  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= 13) p1_log2 = v; }
+  while (p1_log2 < SK_MAX_P1_LOG2 && (seq_len >> p1_log2) > SK_BUCKET_SYMS) ++p1_log2;
+  if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= SK_MAX_P1_LOG2) p1_log2 = v; }
   c->p1_log2 = p1_log2;
   const size_t p1 = (size_t)1 << p1_log2;
   // Runs are cut into records of at most SK_NKMAX windows: the count kernel expands one record per
