@@ -292,10 +292,12 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
   LineReader rd(text, n);
   size_t a = 0, b = 0;
   bool have = rd.next(a, b);
-  auto put_seq = [&](const uint8_t* s, size_t len) {
+  // (upper = false for a wrapped line of a split record that starts with '>': the reference takes every such line
+  // of its piece list for a header and prints it as it stands, lib/mercat2_fasta.py:103-104)
+  auto put_seq = [&](const uint8_t* s, size_t len, bool upper = true) {
     const size_t at = o.size();
     o.insert(o.end(), s, s + len);
-    if (toupper)
+    if (toupper && upper)
       for (size_t i = at; i < o.size(); ++i)
         if (o[i] >= 'a' && o[i] <= 'z') o[i] = (uint8_t)(o[i] - 32);
     o.push_back('\n');
@@ -372,7 +374,7 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
       for (size_t q = i; q < j; q += 80) {
         const size_t len = j - q < 80 ? j - q : 80;
         count_gc(seq.data() + q, len);
-        put_seq(seq.data() + q, len);
+        put_seq(seq.data() + q, len, seq[q] != '>');
       }
       st->pieces += 1;
       if (j >= L) break;

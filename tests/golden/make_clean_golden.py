@@ -57,6 +57,7 @@ def edge_inputs():
         ">s6 crlf\r\nACGTNNAC\r\nGGTT\r\n"
         ">s7 long\n" + "ACGT" * 61 + "N" + "TTGCA" * 40 + "\n"
         ">s8 exactly 80 and 160\n" + "A" * 80 + "N" + "C" * 160 + "N" + "G" * 81 + "\n"
+        ">s12 a piece that starts with the header mark: printed as it stands even with -toupper\nacgtNN>tail\nacgtNNNac>gt\n"
         ">s9\nN\n>s10 empty record\n>s11 no newline at the end\nACGNNNT"
     )
     odd = (
