@@ -82,10 +82,10 @@ int mk_reset(mk_ctx* ctx);
  * lib/mercat2_kmers.py:56-60): with on != 0 every ACGT-only window is counted under
  * min(kmer, reverse-complement(kmer)).  Windows holding other characters keep their own text.
  * Nucleotide alphabet only; call before the first chunk of a sample (or right after mk_reset).
- * LIMIT: k <= 32 (one-word keys).  For 33 <= k <= 64 the call returns MK_ERR_ARG: the two-word path files a
- * window under the minimizer of its FIRST 32 bases, which a window and its reverse complement do not share, so
- * the two strands of a k-mer would meet in different buckets (a strand-symmetric minimizer over both ends of the
- * window is not built).  k > 64 and the raw alphabet count text, which has no complement. */
+ * Nucleotide k <= 64.  One-word keys (k <= 32) file a window under min(11-mer, its reverse complement) of its
+ * minimizer; two-word keys (33 <= k <= 64) under the smallest canonical 11-mer among the candidates of the window's
+ * first and last 32 bases -- the set the two strands share.  k > 64 and the raw alphabet count text, which has no
+ * complement: MK_ERR_ARG. */
 int mk_set_canonical(mk_ctx* ctx, int on);
 
 /* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */

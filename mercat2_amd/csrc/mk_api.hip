@@ -235,7 +235,10 @@ extern "C" int mk_set_canonical(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;
   { int rc_ = settle(c); if (rc_) return rc_; }
   if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_canonical: only the nucleotide alphabet has a reverse complement"; return MK_ERR_ARG; }
-  if (on && c->mode != MK_MODE_DENSE && c->mode != MK_MODE_HASH64) { c->err = "mk_set_canonical: canonical counting is implemented for k <= 32"; return MK_ERR_ARG; }
+  if (on && c->mode != MK_MODE_DENSE && c->mode != MK_MODE_HASH64 && !(c->mode == MK_MODE_HASH128 && c->use_superkmer2)) {
+    c->err = "mk_set_canonical: canonical counting is implemented for nucleotide k <= 64 (two-word keys: on the partitioned path only)";
+    return MK_ERR_ARG;
+  }
   if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->st.chunks) {
     if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->in_chunk)) {
       c->err = "mk_set_canonical: the running table already holds rows counted in the other mode (mk_reset first)";
@@ -499,6 +502,10 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   }
   // partitioned path: no global chunk table (32-bit record indices in the scatter's LDS: chunks below 4 G symbols)
   const bool sk2 = c->mode == MK_MODE_HASH128 && c->use_superkmer2 && seq_len < 0xFFFFFF00ull;
+  if (c->mode == MK_MODE_HASH128 && c->canonical && !sk2) {
+    c->err = "canonical counting of 33..64-mers needs the partitioned path (chunk of 4 G symbols or more)";
+    return MK_ERR_RANGE;
+  }
   if (c->mode == MK_MODE_BYREF || (c->mode == MK_MODE_HASH128 && !sk2)) {
     c->rtab_chunk_slots = pow2_at_least(2 * seq_len);
   } else if (bad_symbols) {

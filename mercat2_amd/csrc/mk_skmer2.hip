@@ -49,6 +49,89 @@ template <class F>
 __device__ __forceinline__ void sk2_walk(const Sk2Runs& r, u64 w0, u64 w1, F&& emit) { sk_walk(r, w0, w1, SK2_NKMAX, false, emit); }
 __device__ __forceinline__ unsigned sk2_bucket(unsigned mm, int p1_log2) { return sk_bucket(mm, p1_log2); }
 
+// ---- canonical mode (opt-in extension, mk_set_canonical): a window and its reverse complement must be filed in the
+// same bucket.  The minimizer of the first 32 bases is not shared by the two strands; the smallest canonical 11-mer
+// among the candidates of the FIRST 32 and of the LAST 32 bases is: position p of a window is position k - 11 - p of
+// its reverse complement, so the two candidate sets {0..21} and {k-32..k-11} swap, and a canonical 11-mer is its own
+// mirror image.  A window is filed under that VALUE (its order hash, a bijection of the 11-mer): runs are windows with
+// equal values.
+template <class F>
+__device__ __forceinline__ void sk2c_region(u64 a0, u64 a1, F&& put) {
+  constexpr int W = 22, NQ = SK_R + W - 1, P = 16;
+  unsigned ord[NQ];
+  unsigned mm = sk_mmer(a0, a1, 0);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q) {
+      const int pos = q + SK_M - 1;
+      const unsigned base = (unsigned)((pos < 32 ? (a0 >> (62 - 2 * pos)) : (a1 >> (62 - 2 * (pos - 32)))) & 3u);
+      mm = ((mm << 2) | base) & SK_MASK;
+    }
+    ord[q] = sk_order_hash(sk_canon_mmer(mm, true));
+  }
+#pragma unroll
+  for (int step = 1; step < P; step <<= 1) {
+#pragma unroll
+    for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
+  }
+#pragma unroll
+  for (int j = 0; j < SK_R; ++j) put(j, min(ord[j], ord[j + W - P]));
+}
+
+struct Sk2CRuns {
+  unsigned valid, starts;
+  unsigned hv[SK_R];  // filing value of every window
+};
+
+__device__ __forceinline__ Sk2CRuns sk2c_analyse(u64 w0, u64 w1, u64 w2, unsigned valid, int k) {
+  Sk2CRuns r;
+  r.valid = valid;
+  sk2c_region(w0, w1, [&](int j, unsigned v) { r.hv[j] = v; });
+  const int d = k - 32;  // 1 .. 32: where the last 32 bases of window 0 start
+  const u64 v0 = d == 32 ? w1 : ((w0 << (2 * d)) | (w1 >> (64 - 2 * d)));
+  const u64 v1 = d == 32 ? w2 : ((w1 << (2 * d)) | (w2 >> (64 - 2 * d)));
+  sk2c_region(v0, v1, [&](int j, unsigned v) { r.hv[j] = min(r.hv[j], v); });
+  unsigned starts = valid & 1u;
+#pragma unroll
+  for (int j = 1; j < SK_R; ++j) {
+    const bool ok = (valid >> j) & 1u, prev = (valid >> (j - 1)) & 1u;
+    starts |= (ok && (!prev || r.hv[j] != r.hv[j - 1])) ? (1u << j) : 0u;
+  }
+  r.starts = starts;
+  return r;
+}
+
+template <class F>
+__device__ __forceinline__ void sk2c_walk(const Sk2CRuns& r, F&& emit) {
+#pragma unroll
+  for (int j = 0; j < SK_R; ++j) {  // (static indices into hv: it lives in registers)
+    if (!((r.starts >> j) & 1u)) continue;
+    const unsigned stop = (r.starts | ~r.valid) & ~((2u << j) - 1);
+    int nk = (stop ? (__ffs(stop) - 1) : SK_R) - j;
+    int at = j;
+    while (nk > 0) {
+      const int take = nk < SK2_NKMAX ? nk : SK2_NKMAX;
+      emit(at, take, r.hv[j]);
+      at += take;
+      nk -= take;
+    }
+  }
+}
+
+// min(key, reverse complement) of a two-word key: k bases left-aligned in {hi, lo}.
+__device__ __forceinline__ u64 sk2_revpairs(u64 x) {  // the 32 two-bit groups of x in reverse order
+  const u64 y = __brevll(x);
+  return ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+}
+__device__ __forceinline__ void sk2_canon128(u64& hi, u64& lo, int k) {
+  // complement, reverse all 64 groups (the 64 - k padding groups, now 'T', come first), shift the k bases back up
+  const u64 a = sk2_revpairs(~lo), b = sk2_revpairs(~hi);
+  const int s = 128 - 2 * k;  // 0 .. 62
+  const u64 nh = s ? ((a << s) | (b >> (64 - s))) : a;
+  const u64 nl = b << s;
+  if (nh < hi || (nh == hi && nl < lo)) { hi = nh; lo = nl; }
+}
+
 // Windows j = 0..31 whose k (<= 64) bases are clean; p0 is a multiple of 32.
 __device__ __forceinline__ unsigned sk2_valid32(const u64* __restrict__ bad, size_t p0, int k) {
   const size_t bi = p0 >> 6;
@@ -91,6 +174,7 @@ __device__ __forceinline__ Sk2Rec sk2_make_record(u64 w0, u64 w1, u64 w2, u64 w3
 
 // ------------------------------------------------------------------------------ hist / scatter
 // (sample_log2 > 0: one pseudo-randomly chosen analysis thread of every 2^sample_log2, as in mk_skmer.hip)
+template <bool CANON>
 __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                   const MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                   u64* __restrict__ khist, int p1_log2, int k,
@@ -108,12 +192,18 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
     const size_t p0 = t * SK2_R;
     if (t >= nthreads_total || p0 >= seq_len) continue;
     const u64 w0 = codes[t], w1 = codes[t + 1];
-    const Sk2Runs r = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
-    sk2_walk(r, w0, w1, [&](int, int nk, unsigned mm) {
+    auto tally = [&](int, int nk, unsigned mm) {
       const unsigned b = sk2_bucket(mm, p1_log2);
       atomicAdd(&lh[b], 1u);
       atomicAdd(&lk[b], (unsigned)nk);
-    });
+    };
+    if constexpr (CANON) {
+      const Sk2CRuns r = sk2c_analyse(w0, w1, codes[t + 2], sk2_valid32(bad, p0, k), k);
+      sk2c_walk(r, tally);
+    } else {
+      const Sk2Runs r = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
+      sk2_walk(r, w0, w1, tally);
+    }
   }
   __syncthreads();
   for (unsigned b = threadIdx.x; b < p1; b += blockDim.x) {
@@ -124,6 +214,7 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
   }
 }
 
+template <bool CANON>
 __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                      MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                      u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
@@ -144,14 +235,23 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
     const size_t t = tile * SK2_SCAT_THREADS + threadIdx.x;
     const size_t p0 = t * SK2_R;
     Sk2Runs runs;
+    Sk2CRuns cruns;  // (canonical mode)
     runs.valid = 0;
     runs.starts = 0;
+    cruns.valid = 0;
+    cruns.starts = 0;
     u64 w0 = 0, w1 = 0;
     if (p0 < seq_len) {
       w0 = codes[t];
       w1 = codes[t + 1];
-      runs = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
-      sk2_walk(runs, w0, w1, [&](int, int, unsigned mm) { atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u); });
+      auto tally = [&](int, int, unsigned mm) { atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u); };
+      if constexpr (CANON) {
+        cruns = sk2c_analyse(w0, w1, codes[t + 2], sk2_valid32(bad, p0, k), k);
+        sk2c_walk(cruns, tally);
+      } else {
+        runs = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
+        sk2_walk(runs, w0, w1, tally);
+      }
     }
     __syncthreads();
     {
@@ -180,14 +280,16 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
       }
     }
     __syncthreads();
-    if (runs.starts) {
+    if (CANON ? cruns.starts : runs.starts) {
       const u64 w2 = codes[t + 2], w3 = codes[t + 3];
-      sk2_walk(runs, w0, w1, [&](int jstart, int nk, unsigned mm) {
+      auto store = [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk2_bucket(mm, p1_log2);
         const unsigned base = gbase[b];
         const unsigned rank = atomicAdd(&lh[b], 1u);
         if (base != ~0u) part[(size_t)base + rank] = sk2_make_record(w0, w1, w2, w3, jstart, nk, k);
-      });
+      };
+      if constexpr (CANON) sk2c_walk(cruns, store);
+      else sk2_walk(runs, w0, w1, store);
     }
     __syncthreads();
     for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
@@ -257,6 +359,7 @@ __device__ __forceinline__ void sk2c_drain(ulonglong2* tkey, unsigned* tcnt, con
   }
 }
 
+template <bool CANON>
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
                                                                const u64* __restrict__ cursor,
                                                                const u64* __restrict__ kstart, u64* __restrict__ nsurv,
@@ -325,6 +428,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
             for (int u = 0; u < SK2_NKMAX; ++u) {
               khi[u] = x0;
               klo[u] = x1 & lomask;
+              if constexpr (CANON) sk2_canon128(khi[u], klo[u], k);
               x0 = (x0 << 2) | (x1 >> 62);
               x1 = (x1 << 2) | (x2 >> 62);
               x2 <<= 2;
@@ -506,22 +610,35 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   const size_t hist_grid = sample_log2 ? 128 : 256;
   (void)kcursor;
   mk_prof_begin(c, MK_K_PART);
-  hipLaunchKernelGGL(mk_sk2_hist_k, dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK2_HIST_THREADS), 0, c->stream,
-                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
+  const dim3 hgrid((unsigned)(tiles < hist_grid ? tiles : hist_grid)), sgrid((unsigned)(stiles < 4096 ? stiles : 4096));
+  if (c->canonical)
+    hipLaunchKernelGGL(mk_sk2_hist_k<true>, hgrid, dim3(SK2_HIST_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                       (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
+  else
+    hipLaunchKernelGGL(mk_sk2_hist_k<false>, hgrid, dim3(SK2_HIST_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                       (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
   mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
                     (u64)surv_cap, sigmas);
-  hipLaunchKernelGGL(mk_sk2_scatter_k, dim3((unsigned)(stiles < 4096 ? stiles : 4096)), dim3(SK2_SCAT_THREADS), 0,
-                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
-                     (Sk2Rec*)c->part.p, p1_log2, k, stiles);
+  if (c->canonical)
+    hipLaunchKernelGGL(mk_sk2_scatter_k<true>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                       (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
+  else
+    hipLaunchKernelGGL(mk_sk2_scatter_k<false>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                       (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
-    hipLaunchKernelGGL(mk_sk2_count_k, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
-                       (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                       (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
+    if (c->canonical)
+      hipLaunchKernelGGL(mk_sk2_count_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
+                         (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
+    else
+      hipLaunchKernelGGL(mk_sk2_count_k<false>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
+                         (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());

@@ -381,7 +381,7 @@ def _fold_filter(table, c):
     return {key: n for key, n in cpu_ref.canonical_fold(table).items() if n >= c}
 
 
-@pytest.mark.parametrize("k", [3, 7, 12, 17, 21, 31, 32])
+@pytest.mark.parametrize("k", [3, 7, 12, 17, 21, 31, 32, 33, 40, 47, 63, 64])
 def test_canonical_mode_is_the_folded_reference(k):
     """Opt-in canonical counting (north_star / BASELINE config 3; NOT reference behaviour):
     oracle = reference counts with min_count 0, every ACGT-only key folded onto
@@ -395,9 +395,10 @@ def test_canonical_mode_is_the_folded_reference(k):
         assert got == _fold_filter(c_oracle.count_dict(data, k, 0), c), (k, c, len(data))
 
 
-def test_canonical_mode_chunked_and_guards():
+@pytest.mark.parametrize("k", [31, 63])
+def test_canonical_mode_chunked_and_guards(k):
     from oracle import c_oracle
-    k, c = 31, 2
+    c = 2
     data = native.synth_reads(30_000, 43, 40_000, 150, 44).tobytes()
     offs = chunk_offsets(data, 2_000_000)
     assert len(offs) > 3
@@ -413,6 +414,8 @@ def test_canonical_mode_chunked_and_guards():
     assert got == want
     with pytest.raises(native.MercatHipError):
         native.Counter(3, native.ALPHABET_AA5, canonical=True)
+    with pytest.raises(native.MercatHipError):
+        native.Counter(70, native.ALPHABET_NT2, canonical=True)  # text keys have no complement
 
 
 def test_run_sample_streams_and_merge_from(tmp_path):
