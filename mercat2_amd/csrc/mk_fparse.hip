@@ -303,8 +303,13 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
     unsigned at = shift + filled + inc - cnt;
 #define FP_BYTE(j) ((uint8_t)(((j) < 4 ? v.x : ((j) < 8 ? v.y : ((j) < 12 ? v.z : v.w))) >> (8 * ((j) & 3))))
     if (out == 0xFFFFu && sep == 0) {
+#ifdef FP_BYTE_STORES
 #pragma unroll
       for (int j = 0; j < 16; ++j) lds[at + j] = FP_BYTE(j);
+#else
+      // all 16 bytes kept: one unaligned 16-byte LDS store (gfx950 takes unaligned DS accesses) instead of 16 byte stores
+      __builtin_memcpy(lds + at, &v, 16);
+#endif
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
