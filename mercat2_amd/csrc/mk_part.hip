@@ -214,6 +214,7 @@ __global__ __launch_bounds__(SCAT_THREADS) void mk_part_scatter_k(const u64* __r
 #define CNT_MAX_PROBE 48  // longer chains mean the table is too full for this sub-range: split it
 __device__ __forceinline__ void lds_insert_slow(u64* tkey, unsigned* tcnt, unsigned* s_overflow, u64 key, unsigned slot,
                                                 u64 cur) {
+#pragma unroll 1  // (unrolled 48 times and inlined at every call site this loop was most of the kernel's 23 KB of code)
   for (int probe = 0; probe < CNT_MAX_PROBE; ++probe) {
     if (cur == MK_EMPTY) {
       cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
