@@ -5,7 +5,10 @@ sys.path.insert(0, ".")
 import numpy as np
 from mercat2_amd import native
 from mercat2_amd.chunker import chunk_offsets
-from oracle import c_oracle
+from oracle import c_oracle, cpu_ref
+
+CANON = "--canonical" in sys.argv  # the opt-in extension: oracle = the chunk's counts at c = 0 folded onto min(key, revcomp), then the filter
+sys.argv = [a for a in sys.argv if a != "--canonical"]
 
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 d = tempfile.mkdtemp(dir="/tmp")
@@ -27,9 +30,13 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
     offs = chunk_offsets(data, size) if size and len(data) >= size else [0, len(data)]
     want = {}
     for a, b in zip(offs[:-1], offs[1:]):
-        for key, n in c_oracle.count_dict(data[a:b], k, c).items():
+        if CANON:
+            table = {key: n for key, n in cpu_ref.canonical_fold(c_oracle.count_dict(data[a:b], k, 0)).items() if n >= c}
+        else:
+            table = c_oracle.count_dict(data[a:b], k, c)
+        for key, n in table.items():
             want[key] = want.get(key, 0) + n
-    ctxs = [native.Counter(k, native.ALPHABET_NT2) for _ in range(rng.choice([1, 2]))]
+    ctxs = [native.Counter(k, native.ALPHABET_NT2, canonical=CANON) for _ in range(rng.choice([1, 2]))]
     try:
         st = native.count_file(ctxs, path, size, c)
         got = ctxs[0].to_dict()
