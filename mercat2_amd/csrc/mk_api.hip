@@ -1311,7 +1311,20 @@ extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
   if (dst->in_chunk || src->in_chunk) { c->err = "mk_merge_from: a chunk is open"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(dst->device));
   int rc;
-  if (src->mode == MK_MODE_DENSE || src->mode == MK_MODE_HASH64 || src->mode == MK_MODE_HASH128) {
+  if (src->mode == MK_MODE_HASH64) {
+    // table to table, on the device: no compaction, no sort (the rows' order does not matter for a sum)
+    if ((rc = settle(src)) != MK_OK) { dst->err = src->err; return rc; }
+    if ((rc = settle(dst)) != MK_OK) return rc;
+    MK_HIP(hipStreamSynchronize(src->stream));
+    if (src->run_rows) {
+      if ((rc = grow_run64(dst, dst->run_rows + src->run_rows)) != MK_OK) return rc;
+      MK_HIP(hipMemsetAsync(dst->info.p, 0, sizeof(MkChunkInfo), dst->stream));
+      if ((rc = mk_launch_merge_table64(dst, (const MkSlot*)src->run.p, src->run_slots)) != MK_OK) return rc;
+      if ((rc = pull_info(dst)) != MK_OK) return rc;
+      dst->run_rows += (size_t)dst->h_info->new_rows;
+    }
+    dst->run_side += src->run_side;
+  } else if (src->mode == MK_MODE_DENSE || src->mode == MK_MODE_HASH128) {
     size_t cap = 0;
     if ((rc = mk_export_size(src, &cap)) != MK_OK) { dst->err = src->err; return rc; }
     cap += 1;

@@ -212,6 +212,8 @@ int mk_launch_rows_gather(mk_ctx* c, const uint8_t* arena, const uint64_t* order
                           uint8_t* out_rows, uint64_t* out_cnts);
 int mk_launch_alpha(mk_ctx* c, unsigned long long* d_out);  // 16 words: see mk_alpha_k
 int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
+// every row of another one-word table (same device) added into c's running table; *new_rows counts the new keys
+int mk_launch_merge_table64(mk_ctx* c, const MkSlot* from, size_t from_slots);
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);

@@ -480,6 +480,15 @@ int mk_launch_refilter_dense(mk_ctx* c, uint64_t* bins, size_t nbins, uint64_t m
   return MK_OK;
 }
 
+int mk_launch_merge_table64(mk_ctx* c, const MkSlot* from, size_t from_slots) {
+  if (!from_slots) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  hipLaunchKernelGGL(mk_accumulate64_k, dim3(grid_for(from_slots, 256, 2048)), dim3(256), 0, c->stream, from, from_slots, (u64)0,
+                     (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows);
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots) {
   if (!from_slots) return MK_OK;
   hipLaunchKernelGGL(mk_rehash64_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots, to,
