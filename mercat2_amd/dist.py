@@ -112,7 +112,11 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
     # rows kept as text: gathered (as objects, through the host) to rank 0 only when some rank has any
     if any(extras):
         gathered = [None] * world if rank == 0 else None
-        dist.gather_object((ex_k, ex_c), gathered, dst=0, group=group)
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):  # (object collectives over RCCL stage through the CURRENT device)
+                dist.gather_object((ex_k, ex_c), gathered, dst=0, group=group)
+        else:
+            dist.gather_object((ex_k, ex_c), gathered, dst=0, group=group)
         if rank == 0:
             for k_arr, c_arr in gathered:
                 ctx.import_exotic(k_arr, c_arr)
