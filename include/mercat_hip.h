@@ -67,6 +67,7 @@ typedef struct mk_stats_t {
   uint64_t records;  /* super-k-mer records written (0 on other paths) */
   uint64_t distinct; /* distinct packed keys seen per chunk, summed over chunks */
   uint64_t part_retries; /* chunks partitioned twice: the sampled bucket sizes were too small somewhere */
+  uint64_t part_reused;  /* chunks that inherited the bucket regions of the chunk before them (no histogram, no scan) */
 } mk_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

@@ -174,6 +174,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   c->use_speculation = getenv("MK_NO_SPECULATION") ? 0 : 1;
+  c->use_reuse = getenv("MK_NO_REUSE") ? 0 : 1;
   if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo), hipHostMallocDefault)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
   if ((rc = mk_buf_reserve(c, c->info, sizeof(MkChunkInfo) + 64)) != MK_OK) return fail(rc, c->err);
@@ -239,6 +240,7 @@ extern "C" int mk_set_canonical(mk_ctx* c, int on) {
     c->err = "mk_set_canonical: canonical counting is implemented for nucleotide k <= 64 (two-word keys: on the partitioned path only)";
     return MK_ERR_ARG;
   }
+  c->part_reuse_ok = false;  // (bucket regions sized in the other mode are not inherited)
   if (c->in_chunk || c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->st.chunks) {
     if ((on != 0) != (c->canonical != 0) && (c->run_rows || c->run_ref_rows || c->run128_rows || c->run_side || c->in_chunk)) {
       c->err = "mk_set_canonical: the running table already holds rows counted in the other mode (mk_reset first)";
@@ -406,6 +408,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     c->err = "counting kernel reported " + std::to_string(h->errors) + " unrecoverable condition(s) (bucket too large to split)";
     return MK_ERR_RANGE;
   }
+  c->part_dirty = false;  // the count kernel ran to its end: every cursor is back at its region's start
   if (!two && h->survivors && (rc = grow_run64(c, c->run_rows + (size_t)h->survivors)) != MK_OK) return rc;
   if (h->survivors_ref && (rc = grow_run_ref(c, c->run_ref_rows + (size_t)h->survivors_ref)) != MK_OK) return rc;
   if (two && (h->survivors || h->survivors_ref) &&
@@ -554,6 +557,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";
     return MK_ERR_RANGE;
   }
+  c->part_dirty = false;
   if (c->mode == MK_MODE_HASH64 && c->h_info->survivors)
     if ((rc = grow_run64(c, c->run_rows + (size_t)c->h_info->survivors)) != MK_OK) return rc;
   if (c->h_info->survivors_ref)
@@ -1168,6 +1172,7 @@ extern "C" int mk_trim(mk_ctx* c) {
     if (!(b == &c->ctab && c->mode == MK_MODE_DENSE)) buf_free(*b);  // the dense bins are allocated once, at mk_create
   if (c->mode != MK_MODE_DENSE) c->ctab_slots = 0;
   c->rtab_chunk_slots = 0;
+  c->part_reuse_ok = false;
   if (c->ingest_ring) { (void)hipHostFree(c->ingest_ring); c->ingest_ring = nullptr; c->ingest_ring_bytes = 0; }
   return MK_OK;
 }

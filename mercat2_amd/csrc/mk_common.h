@@ -151,6 +151,14 @@ struct mk_ctx {
   int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)
   int use_superkmer = 1;
   bool part_sampled = false;  // the last super-k-mer partition sized its buckets from a sample
+  // bucket regions of the previous chunk kept for the next one (mk_skmer.hip): same size, same min_count, no overflow
+  bool part_reuse_ok = false;
+  bool part_dirty = false;    // a partition was launched and its chunk has not been seen to end well (cursors may be anywhere)
+  size_t part_prev_len = 0;
+  int part_prev_p1 = 0;
+  unsigned long long part_prev_minc = 0;
+  int part_cooldown = 0;      // chunks that size their buckets afresh after a chunk overflowed inherited regions
+  int use_reuse = 1;
   int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
   double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk
 
@@ -195,6 +203,7 @@ int mk_launch_count_partitioned(mk_ctx* c, size_t seq_len, uint64_t min_count);
 // super-k-mer form of the same (nt, 18 <= k <= 32): mk_skmer.hip
 int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 // mk_skmer.hip: bucket regions (records and survivors) from an exact or sampled histogram, in one kernel
+bool mk_part_inherit(mk_ctx* c, size_t seq_len, int p1_log2, uint64_t min_count, bool sampled, bool exact);  // mk_skmer.hip
 void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned long long* khist, unsigned long long* start,
                        unsigned long long* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
                        unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas);

@@ -408,7 +408,7 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
 // K32: k == 32, the only k whose keys can equal the free-slot mark (32 x 'T'): that key is counted aside.
 template <bool CANON, bool K32>
 __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
-                                                             const u64* __restrict__ cursor,
+                                                             u64* __restrict__ cursor,
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
@@ -580,6 +580,9 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         first_pass = false;
         STAMP_ADD(tB, t0);
         __syncthreads();  // A: every insert of the pass is in the table
+        // (every wave has long read this bucket's bounds: put its cursor back to the region's start, so that the next
+        // chunk can inherit the regions without a histogram and a scan -- see the launcher)
+        if (threadIdx.x == 0) cursor[b] = lo;
         STAMP_ADD(tF, t0);
         ++npass;
         over = s_overflow[par] != 0;
@@ -709,7 +712,7 @@ void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start,
 
 template <int W, bool CANON>
 static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
-                     u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart) {
+                     u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart, bool reuse) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   float sigmas = 6.0f;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
   if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = (float)atof(e);
@@ -718,11 +721,13 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
   const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
-  hipLaunchKernelGGL((mk_sk_hist_k<W, CANON>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
-                     (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
-                     sample_log2);
-  hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
-                     info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
+  if (!reuse) {  // (reuse: the regions of the previous chunk stand as they are, cursors back at their starts)
+    hipLaunchKernelGGL((mk_sk_hist_k<W, CANON>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
+                       sample_log2);
+    hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
+                       info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
+  }
   hipLaunchKernelGGL((mk_sk_scatter_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
                      c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
                      (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
@@ -731,6 +736,29 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
 #ifdef MK_STAMP
 u64* mk_dbg_ptr = nullptr;
 #endif
+
+// Chunks of one sample are equally long (the Chunker cuts at the first record past the size) and drawn from the
+// same text: a chunk whose predecessor sized its buckets from the sampled histogram -- the estimate plus six
+// standard deviations plus a floor, about twice the mean -- and did not overflow them INHERITS those regions
+// (the count kernel puts every cursor back to its region's start): no histogram, no scan.  A chunk that overflows
+// inherited regions is partitioned again exactly, like one that overflows sampled ones, and the next few chunks
+// size their buckets afresh.  Called once per partition launch (both key widths); true = inherit.
+bool mk_part_inherit(mk_ctx* c, size_t seq_len, int p1_log2, uint64_t min_count, bool sampled, bool exact) {
+  if (c->part_cooldown > 0 && !exact) c->part_cooldown -= 1;
+  const bool reuse = c->use_reuse && !exact && sampled && c->part_reuse_ok && !c->part_dirty && c->part_cooldown == 0 &&
+                     p1_log2 == c->part_prev_p1 && (unsigned long long)min_count == c->part_prev_minc &&
+                     seq_len <= c->part_prev_len + c->part_prev_len / 100 && seq_len >= c->part_prev_len - c->part_prev_len / 50;
+  if (reuse) c->st.part_reused += 1;
+  c->part_dirty = true;  // (until the caller has read the chunk's flags back: process_chunk, process_chunk_fast)
+  if (exact) { c->part_reuse_ok = false; c->part_cooldown = 4; }
+  else if (sampled && !reuse) {
+    c->part_reuse_ok = true;
+    c->part_prev_len = seq_len;
+    c->part_prev_p1 = p1_log2;
+    c->part_prev_minc = (unsigned long long)min_count;
+  } else if (!reuse) c->part_reuse_ok = false;
+  return reuse;
+}
 
 int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact) {
   if (seq_len == 0) return MK_OK;
@@ -760,6 +788,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     if (!exact && seq_len >= min_len) sample_log2 = want;
   }
   c->part_sampled = sample_log2 != 0;
+  const bool reuse = mk_part_inherit(c, seq_len, p1_log2, min_count, sample_log2 != 0, exact);
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   // worst case one record per window
@@ -783,13 +812,13 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   u64* khist = cursor + p1;
   u64* kstart = khist + p1;
   u64* nsurv = kstart + p1 + 1 + p1;  // (the p1 words in between: a cursor array the 8-byte-key path uses)
-  MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
+  if (!reuse) MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   mk_prof_begin(c, MK_K_PART);
   switch (k - SK_M + 1) {
 #define SK_CASE(W)                                                                                                      \
   case W:                                                                                                               \
-    if (c->canonical) launch_wc<W, true>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); \
-    else launch_wc<W, false>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart); \
+    if (c->canonical) launch_wc<W, true>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse); \
+    else launch_wc<W, false>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse); \
     break;
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
     SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
@@ -812,7 +841,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     const int dflags = getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0;
 #define SKC_LAUNCH(CANON, K32)                                                                                          \
   hipLaunchKernelGGL((mk_sk_count_k<CANON, K32>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
-                     (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count,            \
+                     (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
                      (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf, dflags)
     if (c->canonical) { if (k == 32) SKC_LAUNCH(true, true); else SKC_LAUNCH(true, false); }
     else { if (k == 32) SKC_LAUNCH(false, true); else SKC_LAUNCH(false, false); }

@@ -361,7 +361,7 @@ __device__ __forceinline__ void sk2c_drain(ulonglong2* tkey, unsigned* tcnt, con
 
 template <bool CANON>
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
-                                                               const u64* __restrict__ cursor,
+                                                               u64* __restrict__ cursor,
                                                                const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                                MkChunkInfo* __restrict__ info, u64 min_count,
                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
@@ -484,6 +484,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
         }
         if (qcount) sk2c_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
         __syncthreads();  // A
+        if (threadIdx.x == 0) cursor[b] = lo_r;  // back to the region's start: the next chunk may inherit the regions (mk_skmer.hip)
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
         {
@@ -583,6 +584,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     if (!exact && seq_len >= min_len) sample_log2 = want;
   }
   c->part_sampled = sample_log2 != 0;
+  const bool reuse = mk_part_inherit(c, seq_len, p1_log2, min_count, sample_log2 != 0, exact);
   int rc;
   if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   const size_t part_cap = seq_len + 64;
@@ -603,7 +605,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   u64* kstart = khist + p1;
   u64* kcursor = kstart + p1 + 1;
   u64* nsurv = kcursor + p1;
-  MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
+  if (!reuse) MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   const size_t threads = div_up(seq_len, SK2_R);
   const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK2_HIST_THREADS);
   const size_t stiles = div_up(threads, SK2_SCAT_THREADS);
@@ -611,14 +613,17 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   (void)kcursor;
   mk_prof_begin(c, MK_K_PART);
   const dim3 hgrid((unsigned)(tiles < hist_grid ? tiles : hist_grid)), sgrid((unsigned)(stiles < 4096 ? stiles : 4096));
-  if (c->canonical)
+  if (reuse) {
+    // the regions of the chunk before stand as they are, every cursor back at its start
+  } else if (c->canonical)
     hipLaunchKernelGGL(mk_sk2_hist_k<true>, hgrid, dim3(SK2_HIST_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
   else
     hipLaunchKernelGGL(mk_sk2_hist_k<false>, hgrid, dim3(SK2_HIST_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
-  mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
-                    (u64)surv_cap, sigmas);
+  if (!reuse)
+    mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
+                      (u64)surv_cap, sigmas);
   if (c->canonical)
     hipLaunchKernelGGL(mk_sk2_scatter_k<true>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
@@ -633,11 +638,11 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
     if (c->canonical)
       hipLaunchKernelGGL(mk_sk2_count_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
-                         (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                          (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
     else
       hipLaunchKernelGGL(mk_sk2_count_k<false>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
-                         (const u64*)start, (const u64*)cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                          (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
   }
   mk_prof_end(c);

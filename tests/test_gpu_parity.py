@@ -763,6 +763,38 @@ def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_
             assert (retries > 0) == expect_retry, (k, c, sigmas, retries)
 
 
+def test_equal_chunks_inherit_bucket_regions(monkeypatch):
+    """A chunk as long as the one before it (same k, same min_count, no overflow) inherits that chunk's bucket
+    regions instead of sizing its own (mk_stats_t.part_reused).  Same tables as with MK_NO_REUSE; a chunk of the
+    same length whose content does not fit the inherited regions (a repeat array after random reads) is
+    partitioned again exactly, and a shorter last chunk sizes its own."""
+    monkeypatch.setenv("MK_SAMPLE_MIN", "0")
+    from oracle import c_oracle
+    n = 3_000_000
+    reads = [native.synth_reads(n // 152 + 1, 41, 60_000 + 7 * i, 150, 42 + i).tobytes()[:n] for i in range(3)]
+    unit = b"ACGTTGCAAGGCTTAACGGATCCATGCAAGTCC"
+    skew = (b">rep\n" + unit * (n // len(unit)))[: n - 1] + b"\n"
+    assert len(skew) == n
+    for k, c in ((31, 2), (21, 1), (40, 2)):
+        chunks = [reads[0], reads[1], skew, reads[2], reads[1], reads[0][: n // 3]]
+        want = cpu_ref.merge_counts([c_oracle.count_dict(x, k, c) for x in chunks])
+        seen = {}
+        for env in ("", "1"):
+            if env:
+                monkeypatch.setenv("MK_NO_REUSE", env)
+            else:
+                monkeypatch.delenv("MK_NO_REUSE", raising=False)
+            with native.Counter(k, native.ALPHABET_NT2) as ctx:
+                for x in chunks:
+                    ctx.count_chunk(x, c)
+                got = ctx.to_dict()
+                seen[env] = ctx.stats()
+            assert got == want, (k, c, env)
+        assert seen["1"]["part_reused"] == 0
+        assert seen[""]["part_reused"] >= 2, seen[""]
+        assert seen[""]["part_retries"] >= 1, seen[""]     # the repeat array did not fit the reads' regions
+
+
 def test_skewed_genome_like_input_at_scale_vs_c_oracle():
     """60 MB that look like an assembly rather than reads: megabase single-line records, a satellite
     array (171-bp unit, 1 % mutated copies), poly-A, a dinucleotide repeat and N gaps next to random
