@@ -33,7 +33,7 @@ typedef unsigned long long u64;
 #define FP_WAVES (FP_THREADS / 64)
 
 struct FpEntry {  // per wave summary / scan result
-  unsigned a;     // summ: bit0 has_nl, bit1 exit0 ; scan: entry state
+  unsigned a;     // summ: bit0 has_nl, bit1 exit0, bits 2.. separators (header lines that start in the wave)
   unsigned b;     // summ: cnt0 | cnt1 << 16
 };
 
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
     for (size_t w = wave * BW + (size_t)lane; w < b_end && w < bad_words; w += 64) zero_bad[w] = 0ull;
   }
   unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
-  unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, any_nl = 0, flag_low = 0;
+  unsigned s0 = 0, s1 = 1, c0 = 0, c1 = 0, seps = 0, any_nl = 0, flag_low = 0;
 #pragma unroll 1
   for (int sub = 0; sub < FP_SUB; ++sub) {
     const size_t pos = base + (size_t)sub * 1024 + (size_t)lane * 16;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
     unsigned out, sep, bl, last_nl;
     const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
     c0 += __popc(out);
+    seps += __popc(sep);  // '>' at a line start: the same whatever the entry state
     flag_low |= bl;
     if (s1 != s0) {
       unsigned out1, sep1, bl1, ln1;
@@ -163,10 +164,11 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
   for (int d = 32; d > 0; d >>= 1) {
     c0 += __shfl_down(c0, d);
     c1 += __shfl_down(c1, d);
+    seps += __shfl_down(seps, d);
   }
   const bool any_low = __ballot(flag_low != 0) != 0;
   if (lane == 0) {
-    entries[wave].a = any_nl | (s0 << 1);
+    entries[wave].a = any_nl | (s0 << 1) | (seps << 2);
     entries[wave].b = c0 | (c1 << 16);
     if (any_low) atomicOr(&info->parse_fallback, 1ull);
   }
@@ -181,11 +183,12 @@ struct FpScan {
 // One workgroup: thread t owns waves [t*per, (t+1)*per). A wave without a newline passes its
 // entry state through (or-ed with its own exit0); one with a newline resets it to exit0.
 __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict__ entries, size_t nwaves,
-                                                       FpScan* __restrict__ scan, MkChunkInfo* __restrict__ info) {
+                                                       FpScan* __restrict__ scan, MkChunkInfo* __restrict__ info,
+                                                       u64* __restrict__ bad) {
   const size_t per = (nwaves + 1023) / 1024;
   const size_t lo = (size_t)threadIdx.x * per, hi = (lo + per < nwaves) ? lo + per : nwaves;
   unsigned e0 = 0, e1 = 1, has = 0;  // running map of this thread's range
-  u64 c0 = 0, c1 = 0;
+  u64 c0 = 0, c1 = 0, nsep = 0;
   for (size_t w0 = lo; w0 < hi; w0 += 8) {
     FpEntry en[8];  // 8 independent loads in flight, then the (serial) state update
 #pragma unroll
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
       if (w0 + i >= hi) break;
       const unsigned wnl = en[i].a & 1u, wx0 = (en[i].a >> 1) & 1u;
       const unsigned k0 = en[i].b & 0xFFFFu, k1 = en[i].b >> 16;
+      nsep += en[i].a >> 2;
       c0 += e0 ? k1 : k0;
       c1 += e1 ? k1 : k0;
       e0 = wnl ? wx0 : (e0 | wx0);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
   //      (generate = range ends in a header whatever its entry, propagate = range has no newline)
   __shared__ unsigned long long w_G[16], w_P[16];
   __shared__ unsigned w_cin[16];
-  __shared__ u64 w_cnt[16];
+  __shared__ u64 w_cnt[16], w_sep[16];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const u64 G = __ballot(e0 != 0), P = __ballot(has == 0);
   if (lane == 0) { w_G[wv] = G; w_P[wv] = P; }
@@ -236,17 +240,32 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
     const u64 up = __shfl_up(inc, d);
     if (lane >= d) inc += up;
   }
+  for (int d = 32; d > 0; d >>= 1) nsep += __shfl_down(nsep, d);
   if (lane == 63) w_cnt[wv] = inc;
+  if (lane == 0) w_sep[wv] = nsep;
   __syncthreads();
   u64 off = inc - mine;
-  u64 total = 0;
+  u64 total = 0, seps = 0;
 #pragma unroll
   for (int w = 0; w < 16; ++w) {
     const u64 v = w_cnt[w];
     if (w < wv) off += v;
     total += v;
+    seps += w_sep[w];
   }
-  if (threadIdx.x == 0) info->seq_len = total;
+  if (threadIdx.x == 0) {
+    info->seq_len = total;
+    info->symbols = total - seps;  // kept bytes that are not separators
+    if (bad) {  // symbols past the end of seq are "bad" (fused pack): tail of the last word + 3 more words.  The summary
+                // pass has cleared the bitmap; the emit pass only ORs into the (partial) last word and never touches the
+                // words behind it
+      if (total & 63) atomicOr(&bad[total >> 6], ~0ull << (total & 63));
+      const u64 w = (total + 63) >> 6;
+      bad[w] = ~0ull;
+      bad[w + 1] = ~0ull;
+      bad[w + 2] = ~0ull;
+    }
+  }
   for (size_t w0 = lo; w0 < hi; w0 += 8) {
     FpEntry en[8];
 #pragma unroll
@@ -280,7 +299,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   unsigned prev_nl = (base <= begin) ? 1u : ((raw[base - 1] == 10 || raw[base - 1] == 13) ? 1u : 0u);
   unsigned state = sc.st;
   unsigned filled = 0;   // bytes emitted so far by this wave
-  unsigned nsym = 0;
+  int nbad = 0;          // kept characters outside the alphabet (separators subtracted: they are marked bad, not counted)
   unsigned nhi = 0;      // KEPT bytes >= 0x80: sequence characters the reference would decode as multi-byte text
                          // (bytes of header lines never enter a k-mer: lib/mercat2_kmers.py:52-53)
 #pragma unroll 1
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
     state = wave_step(nl, gt, st, low, prev_nl, state, out, sep, bl, last_nl);
     prev_nl = last_nl;
     const unsigned cnt = __popc(out);
-    nsym += cnt - __popc(sep);
+    nbad -= (int)__popc(sep);
     nhi += __popc(hi & out & ~sep);
     unsigned inc = cnt;  // inclusive scan over the wave
 #pragma unroll
@@ -342,15 +361,15 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   //      zero-initialised arrays (the neighbouring wave ORs its part).
   if (codes) {
     const u64 g0 = sc.off, g1 = sc.off + filled;
-    unsigned nbad = 0;
     for (u64 b = (g0 >> 6) + lane; b < ((g1 + 63) >> 6); b += 64) {
       const u64 s_lo = b << 6, s_hi = s_lo + 64;
       const u64 lo = s_lo > g0 ? s_lo : g0, hi = s_hi < g1 ? s_hi : g1;
       u64 w0 = 0, w1 = 0, bd = 0;
-      // always the 64-byte vector path; symbols of the word outside [lo, hi) (another wave's, or
-      // past the end: whatever the LDS slack holds) are masked off -- no divergent byte loop
-      const u64 in_lo = lo - s_lo, in_n = hi - lo;  // valid symbols: in_lo .. in_lo+in_n-1
-      const u64 inmask = (in_n >= 64 ? ~0ull : ((1ull << in_n) - 1)) << in_lo;
+      // always the 64-byte vector path, four characters per 32-bit operation:
+      //   code      = ((ch >> 1) & 3) ^ ((ch >> 2) & 1)      A 0, C 1, G 2, T 3 (any other byte: something in 0..3)
+      //   expected  = "ACGT"[code]   (one v_perm_b32 with the codes as byte selectors)
+      //   bad       = expected != ch (non-zero byte test), its code cleared
+      //   8 bits of codes, first character on top = (codes * 0x40100401) >> 24
       const uint4* p = reinterpret_cast<const uint4*>(lds + (long)shift + (long)(s_lo - g0));  // 16-byte aligned
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -358,60 +377,45 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const unsigned ch = (xd >> (8 * e)) & 0xFFu;
-            const int j = q * 16 + d * 4 + e;
-            const bool in = (inmask >> j) & 1ull;
-            const bool ok = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
-            const u64 code = (ok && in) ? (u64)(((ch >> 1) & 3u) ^ ((ch >> 2) & 1u)) : 0ull;
-            if (j < 32) w0 |= code << (62 - 2 * j); else w1 |= code << (62 - 2 * (j - 32));
-            bd |= (!ok && in) ? (1ull << j) : 0ull;
-            nbad += (!ok && in && ch != MK_SEP) ? 1u : 0u;
-          }
+          const unsigned c = ((xd >> 1) & 0x03030303u) ^ ((xd >> 2) & 0x01010101u);
+          const unsigned df = __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ xd;
+          const unsigned nz = ((((df & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | df) >> 7) & 0x01010101u;  // 1 in every bad byte
+          const unsigned g = ((c & ~(nz | (nz << 1))) * 0x40100401u) >> 24;
+          const unsigned b4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;  // character e of the four -> bit e
+          const int idx = q * 4 + d;  // characters 4 idx .. 4 idx + 3 of the word
+          if (idx < 8) w0 |= (u64)g << (56 - 8 * idx); else w1 |= (u64)g << (56 - 8 * (idx - 8));
+          bd |= (u64)b4 << (4 * idx);
         }
       }
-      if (in_n == 64) {
+      if (hi - lo == 64) {
         codes[2 * b] = w0;
         codes[2 * b + 1] = w1;
         bad[b] = bd;
       } else {
+        // symbols of the word outside [lo, hi) (another wave's, or past the end: whatever the LDS slack holds) are
+        // masked off; the neighbouring wave ORs its part in
+        const unsigned a = (unsigned)(lo - s_lo), e = (unsigned)(hi - s_lo);  // valid symbols a .. e-1, a < e
+        const u64 inmask = ((e - a) >= 64 ? ~0ull : ((1ull << (e - a)) - 1)) << a;
+        const unsigned a0 = a < 32 ? a : 32, e0 = e < 32 ? e : 32, a1 = a > 32 ? a - 32 : 0, e1 = e > 32 ? e - 32 : 0;
+        // symbol j of a word sits at bits 63-2j, 62-2j: symbols x .. y-1 are the bit range [64-2y, 64-2x)
+        const u64 m0 = a0 < e0 ? ((~0ull >> (2 * a0)) & ~(e0 == 32 ? 0ull : (~0ull >> (2 * e0)))) : 0ull;
+        const u64 m1 = a1 < e1 ? ((~0ull >> (2 * a1)) & ~(e1 == 32 ? 0ull : (~0ull >> (2 * e1)))) : 0ull;
+        w0 &= m0;
+        w1 &= m1;
+        bd &= inmask;
         if (w0) atomicOr(&codes[2 * b], w0);
         if (w1) atomicOr(&codes[2 * b + 1], w1);
         if (bd) atomicOr(&bad[b], bd);
       }
+      nbad += (int)__popcll(bd);
     }
-    for (int d = 32; d > 0; d >>= 1) nbad += __shfl_down(nbad, d);
-    if (lane == 0 && nbad) atomicAdd(&info->bad_symbols, (u64)nbad);
   }
-  for (int d = 32; d > 0; d >>= 1) nsym += __shfl_down(nsym, d);
-  if (lane == 0) scan[wave].pad = nsym;  // summed by mk_fparse_total (no hot atomic)
+  // (without the fused pack nobody reads the sum: the pack kernel counts the bad symbols)
+  for (int d = 32; d > 0; d >>= 1) nbad += __shfl_down(nbad, d);
+  if (codes && lane == 0 && nbad > 0) atomicAdd(&info->bad_symbols, (u64)nbad);
   if (__ballot(nhi != 0)) {  // (never, for ASCII input)
     for (int d = 32; d > 0; d >>= 1) nhi += __shfl_down(nhi, d);
     if (lane == 0) atomicAdd(&info->non_ascii, (u64)nhi);
-  }
-}
-
-__global__ __launch_bounds__(1024) void mk_fparse_total(const FpScan* __restrict__ scan, size_t nwaves,
-                                                        MkChunkInfo* __restrict__ info, u64* __restrict__ bad) {
-  __shared__ u64 part[16];
-  u64 s = 0;
-  for (size_t w = threadIdx.x; w < nwaves; w += 1024) s += scan[w].pad;
-  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 t = 0;
-    for (int i = 0; i < 16; ++i) t += part[i];
-    info->symbols = t;
-    if (bad) {  // symbols past the end of seq are "bad" (fused pack): tail of the last word + 3 more words
-      const u64 n = info->seq_len;
-      if (n & 63) atomicOr(&bad[n >> 6], ~0ull << (n & 63));
-      const u64 w = (n + 63) >> 6;
-      bad[w] = ~0ull;
-      bad[w + 1] = ~0ull;
-      bad[w + 2] = ~0ull;
-    }
   }
 }
 
@@ -439,10 +443,9 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, 
   mk_prof_begin(c, MK_K_PARSE);
   hipLaunchKernelGGL(mk_fparse_summ, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, entries, info, codes, bad,
                      2 * bad_words, bad_words);  // (the summary pass clears the packed words and the bad bitmap)
-  hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info);
+  hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info, bad);
   hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, scan,
                      (uint8_t*)c->seq.p, info, codes, bad);
-  hipLaunchKernelGGL(mk_fparse_total, dim3(1), dim3(1024), 0, c->stream, (const FpScan*)scan, nwaves, info, bad);
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
   return MK_OK;
