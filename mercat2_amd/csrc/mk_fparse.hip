@@ -54,26 +54,30 @@ __device__ __forceinline__ uint4 classify16(const uint8_t* __restrict__ raw, siz
     }
     v = make_uint4(w0, w1, w2, w3);
   }
-  nl = gt = st = low = 0;
-  hi = 0;  // mask of the bytes >= 0x80 (only the emit pass uses it: there it is known which bytes are kept)
+  // Four bytes per 32-bit operation.  FP_NZ7(t): bit 7 of every byte of t that is not zero (the other bits are
+  // garbage); so ~FP_NZ7(x ^ pattern) & 0x80808080 flags the bytes equal to the pattern.  A v_dot4_u32_u8 with the
+  // weights 1,2,4,8 (16,..,128 for the odd words) then lines the four flags of a word up as a nibble: two words
+  // accumulate into 128 x (8 mask bits).  (Byte by byte this took twice the instructions.)
+#define FP_NZ7(t) ((((t) & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | (t))
+  unsigned a_nl[2] = {0, 0}, a_gt[2] = {0, 0}, a_st[2] = {0, 0}, a_lo[2] = {0, 0}, a_hi[2] = {0, 0};
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));  // no array: stays in registers
-    // bits 7, 15, 23, 31 -> bits 0..3: the multiply lines them up at bits 21..24
-    hi |= (((((xd & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * d);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const unsigned c = (xd >> (8 * e)) & 0xFFu;
-      const unsigned bit = 1u << (d * 4 + e);
-      // branch-free selects: with `if (...) mask |= bit` hipcc sinks the OR behind a selected
-      // POINTER to the masks and parks all four in scratch memory
-      const bool is_nl = (c == 10u) | (c == 13u);
-      nl |= is_nl ? bit : 0u;
-      gt |= (c == 62u) ? bit : 0u;
-      st |= (c == 42u) ? bit : 0u;
-      low |= (c <= 32u && !is_nl) ? bit : 0u;
-    }
+    const unsigned K = (d & 1) ? 0x80402010u : 0x08040201u;
+    const unsigned notnl = FP_NZ7(xd ^ 0x0A0A0A0Au) & FP_NZ7(xd ^ 0x0D0D0D0Du);
+    const unsigned ge21 = ((xd & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | xd;  // bit 7: byte >= 0x21
+    a_nl[d >> 1] = __builtin_amdgcn_udot4(~notnl & 0x80808080u, K, a_nl[d >> 1], false);
+    a_gt[d >> 1] = __builtin_amdgcn_udot4(~FP_NZ7(xd ^ 0x3E3E3E3Eu) & 0x80808080u, K, a_gt[d >> 1], false);
+    a_st[d >> 1] = __builtin_amdgcn_udot4(~FP_NZ7(xd ^ 0x2A2A2A2Au) & 0x80808080u, K, a_st[d >> 1], false);
+    a_lo[d >> 1] = __builtin_amdgcn_udot4(~ge21 & notnl & 0x80808080u, K, a_lo[d >> 1], false);  // <= 0x20, not a newline
+    a_hi[d >> 1] = __builtin_amdgcn_udot4(xd & 0x80808080u, K, a_hi[d >> 1], false);
   }
+#undef FP_NZ7
+  nl = (a_nl[0] >> 7) | ((a_nl[1] >> 7) << 8);
+  gt = (a_gt[0] >> 7) | ((a_gt[1] >> 7) << 8);
+  st = (a_st[0] >> 7) | ((a_st[1] >> 7) << 8);
+  low = (a_lo[0] >> 7) | ((a_lo[1] >> 7) << 8);
+  hi = (a_hi[0] >> 7) | ((a_hi[1] >> 7) << 8);  // bytes >= 0x80 (only the emit pass uses it: there it is known which bytes are kept)
   return v;
 }
 
