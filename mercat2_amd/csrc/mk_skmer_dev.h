@@ -13,13 +13,13 @@
 // "smallest hash" is a strict total order on 11-mer values: two positions tie only when they hold
 // the same 11-mer, and then either choice names the same minimizer. (The canonical mode relies on
 // this: a window and its reverse complement see the candidates in opposite order.)
-__device__ __forceinline__ unsigned sk_order_hash(unsigned mm) {
-  // 24-bit multiplies (full rate on CDNA; a 32-bit v_mul_lo_u32 issues at a quarter of it): the low
-  // 22 bits of mm * odd + c are a bijection, the xor-shift folds the well-mixed high bits down.
-  unsigned h = (__umul24(mm, 0x9277B5u) + 0x2C5A3Du) & SK_MASK;
-  h ^= h >> 11;
-  return h;
+__device__ __forceinline__ unsigned sk_order_raw(unsigned mm) {
+  // One 24-bit multiply-add (full rate on CDNA; a 32-bit v_mul_lo_u32 issues at a quarter of it): the low 22 bits
+  // of mm * odd + c are a bijection of the 11-mer, and an order compares from the top bit down, where every bit of
+  // mm has been multiplied in -- no xor-shift needed (measured: the same number of records per chunk).
+  return __umul24(mm, 0x9277B5u) + 0x2C5A3Du;
 }
+__device__ __forceinline__ unsigned sk_order_hash(unsigned mm) { return sk_order_raw(mm) & SK_MASK; }
 // 11-mer under which a window is filed: itself, or min(itself, reverse complement) in canonical mode.
 __device__ __forceinline__ unsigned sk_canon_mmer(unsigned mm, bool canon) {
   if (!canon) return mm;
@@ -71,7 +71,7 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, unsigned valid, boo
         const unsigned base = (unsigned)((pos < 32 ? (w0 >> (62 - 2 * pos)) : (w1 >> (62 - 2 * (pos - 32)))) & 3u);
         mm = ((mm << 2) | base) & SK_MASK;
       }
-      ord[q] = (sk_order_hash(sk_canon_mmer(mm, canon)) << 6) | (unsigned)q;
+      ord[q] = (sk_order_raw(sk_canon_mmer(mm, canon)) << 10) | (unsigned)q;  // (the hash's low 22 bits on top, bits 6..9 zero)
     }
   }
   constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;

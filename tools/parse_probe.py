@@ -20,6 +20,6 @@ with native.Counter(31, native.ALPHABET_NT2) as ctx:
             except Exception as e:  # (ablation builds produce nonsense downstream of the parser)
                 print("chunk failed:", str(e)[:80])
     st = ctx.stats()
-    print("bytes/chunk %d  parse %.1f us  part %.1f us  count %.1f us  filter %.1f us  rows %d  reused %d" % (
+    print("bytes/chunk %d  parse %.1f us  part %.1f us  count %.1f us  filter %.1f us  rows %d  reused %d  records/chunk %d  retries %d" % (
         buf.numel(), 1e3 * st["ms_parse"] / max(1, st["n_parse"]), 1e3 * st["ms_part"] / max(1, st["n_part"]),
-        1e3 * st["ms_count"] / max(1, st["n_count"]), 1e3 * st["ms_filter"] / max(1, st["n_filter"]), st["rows"], st["part_reused"]))
+        1e3 * st["ms_count"] / max(1, st["n_count"]), 1e3 * st["ms_filter"] / max(1, st["n_filter"]), st["rows"], st["part_reused"], st["records"] // max(1, st["chunks"]), st["part_retries"]))
