@@ -89,12 +89,15 @@ __device__ __forceinline__ void sk_for_each_record(u64 w0, u64 w1, u64 badw, int
 }
 
 __device__ __forceinline__ ulonglong2 sk_make_record(u64 w0, u64 w1, int jstart, int nk, int k) {
-  u64 hi = jstart ? ((w0 << (2 * jstart)) | (w1 >> (64 - 2 * jstart))) : w0;
-  u64 lo = jstart ? (w1 << (2 * jstart)) : w1;
-  const int L = nk + k - 1;  // bases, <= 61
-  if (L <= 32) { hi = (L == 32) ? hi : (hi & (~0ull << (64 - 2 * L))); lo = 0; }
-  else lo &= ~0ull << (128 - 2 * L);
-  lo |= (u64)nk;
+  // (w0:w1) << 2 jstart, its top 2 L bits kept, nk in the low bits -- selects, no branches: the walk's lanes diverge enough
+  const int s = 2 * jstart;  // 0 .. 62
+  u64 hi = (w0 << s) | ((w1 >> 1) >> (63 - s));
+  u64 lo = w1 << s;
+  const int t = 2 * (nk + k - 1);  // bits of the record's bases, <= 122
+  const u64 mh = t >= 64 ? ~0ull : (~0ull << ((64 - t) & 63));
+  const u64 ml = t <= 64 ? 0ull : (~0ull << ((128 - t) & 63));
+  hi &= mh;
+  lo = (lo & ml) | (u64)nk;
   return make_ulonglong2(hi, lo);
 }
 
@@ -308,10 +311,13 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
       sk_walk(runs, w0, w1, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
         const unsigned b = sk_bucket(mm, p1_log2);
         const unsigned at = atomicAdd(&lh[b], 1u);  // base + rank
+        // (the record is built while the LDS answers: pinned here, or the compiler sinks it behind the test of `at`)
+        ulonglong2 rec = sk_make_record(w0, w1, jstart, nk, k);
+        asm volatile("" : "+v"(rec.x), "+v"(rec.y));
 #ifdef SK_ABL_NOSTORE   // (timing ablation only: the record is built and dropped)
-        if (at == 0xFFFFFFFFu) part[(size_t)at] = sk_make_record(w0, w1, jstart, nk, k);
+        if (at == 0xFFFFFFFFu) part[(size_t)at] = rec;
 #else
-        if (at < SK_NOFIT) part[(size_t)at] = sk_make_record(w0, w1, jstart, nk, k);
+        if (at < SK_NOFIT) part[(size_t)at] = rec;
 #endif
       });
     }

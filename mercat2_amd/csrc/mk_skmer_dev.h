@@ -30,10 +30,11 @@ __device__ __forceinline__ unsigned sk_bucket(unsigned mm, int p1_log2) { return
 
 // 11-mer starting at base q of the 64-base pair (w0,w1).
 __device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
-  u64 x;
-  if (q == 0) x = w0;
-  else if (q < 32) x = (w0 << (2 * q)) | (w1 >> (64 - 2 * q));
-  else x = w1 << (2 * (q - 32));  // q + SK_M <= 64: the 11-mer lies inside w1
+  // (selects and one funnel, no branches: q differs from lane to lane; q + SK_M <= 64, so from q = 32 on the 11-mer
+  // lies inside w1)
+  const u64 a = q < 32 ? w0 : w1, b = q < 32 ? w1 : 0ull;
+  const int s = 2 * (q & 31);
+  const u64 x = (a << s) | ((b >> 1) >> (63 - s));
   return (unsigned)(x >> (64 - 2 * SK_M));
 }
 
