@@ -328,6 +328,159 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
   if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
 
+// The same scatter with the walks FLATTENED.  In the kernel above every lane walks its own runs, and a loop over
+// runs lasts as long as the lane with the most of them: 4.9 runs per thread on average, about 10 for the slowest of
+// 64 lanes, so the two walks (two thirds of the kernel's instructions) run half empty.  Here a lane only LISTS its
+// runs -- one 32-bit item {lane, first window, windows, minimizer position} per record, written into the wave's
+// queue in LDS at a position from a wave prefix sum -- and the wave then works the queue off 64 items at a time with
+// every lane busy: pass 1 finds each item's bucket (the words of the lane that listed it come from LDS), counts it
+// and writes the bucket into the item; pass 2 needs nothing but the item and those words.  Nothing of the analysis
+// lives across the reservation.  A wave whose runs do not fit its queue (SKQ_CAP items per sub-tile: 8 per lane, the
+// mean is below 5) walks that sub-tile the old way and analyses it again in pass 2 -- rare, content-dependent, exact.
+#ifndef SKQ_CAP
+#define SKQ_CAP 512
+#endif
+#define SKQ_WAVES (SK_SCAT_THREADS / 64)
+#define SKQ_WALKED 0xFFFFFFFFu
+template <int W, bool CANON>
+__global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                         MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
+                                                         u64* __restrict__ cursor, ulonglong2* __restrict__ part,
+                                                         int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap) {
+  __shared__ unsigned lh[SK_MAX_P1];  // as above: counts, then base + rank
+  __shared__ ulonglong2 pk_w[SK_SCAT_SUBT][SK_SCAT_THREADS];          // every thread's two words
+  __shared__ unsigned queue[SK_SCAT_SUBT][SKQ_WAVES][SKQ_CAP];        // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
+  __shared__ unsigned s_abort;
+  if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
+  __syncthreads();
+  if (s_abort) return;  // the regions do not fit the buffers: nothing may be written
+  unsigned spilled = 0;
+  constexpr int NB = SK_MAX_P1 / SK_SCAT_THREADS;
+  const unsigned p1 = 1u << p1_log2;
+  const size_t seq_len = info->seq_len;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    unsigned qn[SK_SCAT_SUBT];  // items queued per sub-tile (wave-uniform), or SKQ_WALKED
+#pragma unroll
+    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
+      const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+      const size_t p0 = t * SK_R;
+      SkRuns runs;
+      runs.valid = 0;
+      runs.starts = 0;
+      runs.pos[0] = runs.pos[1] = runs.pos[2] = runs.pos[3] = 0;
+      u64 ww0 = 0, ww1 = 0;
+      if (p0 < seq_len) {
+        ww0 = codes[t];
+        ww1 = codes[t + 1];
+        runs = sk_analyse<W>(ww0, ww1, sk_valid32(bad_window(bad, p0), k), CANON);
+      }
+      pk_w[st][threadIdx.x] = make_ulonglong2(ww0, ww1);
+      const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, nkmax);
+      const unsigned cnt = __popc(s2);
+      unsigned inc = cnt;  // inclusive scan over the wave
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+      }
+      const unsigned total = __shfl(inc, 63);
+      unsigned* const myq = queue[st][wv];
+      if (total <= qcap) {  // (qcap <= SKQ_CAP; tests lower it to walk some or all waves)
+        unsigned todo = s2, at = inc - cnt;
+        while (todo) {
+          const int j = __ffs(todo) - 1;
+          todo &= todo - 1;
+          const unsigned stop = (s2 | ~runs.valid) & ~((2u << j) - 1);
+          const int nk = (stop ? (__ffs(stop) - 1) : SK_R) - j;
+          const u64 pw = j < 10 ? runs.pos[0] : (j < 20 ? runs.pos[1] : (j < 30 ? runs.pos[2] : runs.pos[3]));
+          const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
+          myq[at++] = (unsigned)lane | ((unsigned)j << 6) | ((unsigned)nk << 11) | (best << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the wave's own LDS writes, read by other lanes below)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (unsigned base = 0; base < total; base += 64) {
+          const unsigned i = base + lane;
+          if (i < total) {
+            const unsigned it = myq[i];
+            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
+            const unsigned mm = sk_canon_mmer(sk_mmer(w.x, w.y, (int)(it >> 16)), CANON);
+            const unsigned b = sk_bucket(mm, p1_log2);
+            atomicAdd(&lh[b], 1u);
+            myq[i] = (it & 0xFFFFu) | (b << 16);
+          }
+        }
+        qn[st] = total;
+      } else {
+        if (p0 < seq_len)
+          sk_walk(runs, ww0, ww1, nkmax, CANON, [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+        qn[st] = SKQ_WALKED;
+      }
+    }
+    __syncthreads();
+    {
+      unsigned v[NB];
+      u64 r[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        v[i] = b < p1 ? lh[b] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
+        if (b < p1) {
+          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+          spilled |= fits ? 0u : 1u;
+          lh[b] = fits ? (unsigned)r[i] : SK_NOFIT;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
+      if (qn[st] != SKQ_WALKED) {
+        const unsigned total = qn[st];
+        const unsigned* const myq = queue[st][wv];
+        for (unsigned base = 0; base < total; base += 64) {
+          const unsigned i = base + lane;
+          if (i < total) {
+            const unsigned it = myq[i];
+            const unsigned at = atomicAdd(&lh[it >> 16], 1u);  // base + rank
+            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
+            ulonglong2 rec = sk_make_record(w.x, w.y, (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
+            asm volatile("" : "+v"(rec.x), "+v"(rec.y));  // (built while the LDS answers)
+            if (at < SK_NOFIT) part[(size_t)at] = rec;
+          }
+        }
+      } else {
+        const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+        const size_t p0 = t * SK_R;
+        if (p0 < seq_len) {
+          const ulonglong2 w = pk_w[st][threadIdx.x];
+          const SkRuns runs = sk_analyse<W>(w.x, w.y, sk_valid32(bad_window(bad, p0), k), CANON);
+          sk_walk(runs, w.x, w.y, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
+            const unsigned at = atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u);
+            if (at < SK_NOFIT) part[(size_t)at] = sk_make_record(w.x, w.y, jstart, nk, k);
+          });
+        }
+      }
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+  if (spilled) atomicOr(&info->part_overflow, 4ull);
+}
+
 // ------------------------------------------------------------------------------ 4 count
 // What the insert costs (measured, tools/lds_probe.hip and the ISA of the round-1 kernel): the kernel is
 // bound by VALU issue, not by the LDS.  One compare-and-swap plus one add per key take ~30 clocks of the
@@ -734,9 +887,17 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
     hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, (const u64*)hist, (const u64*)khist, start, cursor, kstart,
                        info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
   }
-  hipLaunchKernelGGL((mk_sk_scatter_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
-                     c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
-                     (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
+  static const bool walked = getenv("MK_SCATTER_WALK") != nullptr;  // (the per-lane walks of the first version, for A/B runs)
+  unsigned qcap = SKQ_CAP;
+  if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && v < SKQ_CAP) qcap = (unsigned)v; }
+  if (walked)
+    hipLaunchKernelGGL((mk_sk_scatter_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
+                       c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
+                       (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
+  else
+    hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
+                       c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
+                       (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, qcap);
 }
 
 #ifdef MK_STAMP

@@ -122,3 +122,17 @@ __device__ __forceinline__ void sk_walk(const SkRuns& r, u64 w0, u64 w1, int nkm
   }
 }
 
+// Run starts with the cuts put in: a run longer than nkmax windows is cut every nkmax windows (what sk_walk does on
+// the fly), so that every set bit is one record.
+__device__ __forceinline__ unsigned sk_cut_starts(unsigned starts, unsigned valid, int nkmax) {
+  if (nkmax >= SK_R) return starts;
+  const unsigned cont = valid & ~starts;  // windows that continue their run
+  unsigned a = cont;                      // a[p] = cont[p - nkmax + 1 .. p] all set
+  int len = 1;
+  while (2 * len <= nkmax) { a &= a << len; len *= 2; }
+  if (len < nkmax) a &= a << (nkmax - len);
+  unsigned s2 = starts;
+  for (unsigned c = (starts << nkmax) & a; c; c = (c << nkmax) & a) s2 |= c;
+  return s2;
+}
+

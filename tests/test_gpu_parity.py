@@ -795,6 +795,26 @@ def test_equal_chunks_inherit_bucket_regions(monkeypatch):
         assert seen[""]["part_retries"] >= 1, seen[""]     # the repeat array did not fit the reads' regions
 
 
+@pytest.mark.parametrize("qcap", ["0", "300", None])
+def test_scatter_queue_and_walk_agree(monkeypatch, qcap):
+    """The scatter lists a wave's runs in an LDS queue and works them off with every lane busy; a wave whose runs do
+    not fit the queue walks them lane by lane instead (and analyses the sub-tile again for the second pass).
+    MK_SKQ_CAP lowers the queue's capacity: 0 walks every wave, 300 about half of them (k = 21: ~6 runs per
+    thread), unset is the product setting; MK_SCATTER_WALK is the first version of the kernel.  Same tables."""
+    from oracle import c_oracle
+    if qcap is not None:
+        monkeypatch.setenv("MK_SKQ_CAP", qcap)
+    data = native.synth_reads(300_000, 5, 70_000, 150, 6).tobytes()
+    low = b">poly\n" + b"A" * 20_000 + b"\n>n\n" + (b"ACGTTGCAAGGCTTAACGGATCCATGCAAGTCCN" * 1500) + b"\n"
+    for k, c, canon in ((21, 2, False), (31, 1, False), (18, 1, False), (32, 2, False), (25, 1, True)):
+        payload = data + low
+        want = _fold_filter(c_oracle.count_dict(payload, k, 0), c) if canon else c_oracle.count_dict(payload, k, c)
+        with native.Counter(k, native.ALPHABET_NT2, canonical=canon) as ctx:
+            ctx.count_chunk(payload, c)
+            got = ctx.to_dict()
+        assert got == want, (k, c, canon, qcap)
+
+
 def test_skewed_genome_like_input_at_scale_vs_c_oracle():
     """60 MB that look like an assembly rather than reads: megabase single-line records, a satellite
     array (171-bp unit, 1 % mutated copies), poly-A, a dinucleotide repeat and N gaps next to random
