@@ -128,8 +128,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = every rank its own sample of --reads reads; strong = the chunks of ONE sample dealt i mod N")
     ap.add_argument("--reads", type=int, default=READS, help="reads per sample (default: the BASELINE workload)")
