@@ -291,7 +291,8 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
                                                              MkChunkInfo* __restrict__ info, u64* __restrict__ codes,
                                                              u64* __restrict__ bad) {
   // 64 bytes of slack on both sides: the fused pack reads whole 64-symbol words around the ends
-  __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][64 + FP_WAVE_BYTES + 32 + 64];
+  // (+ 256: one dump word per lane for the bytes a lane drops, see the compaction below)
+  __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][64 + FP_WAVE_BYTES + 32 + 64 + 256];
   const int wv = threadIdx.x >> 6;
   const size_t wave = (size_t)blockIdx.x * FP_WAVES + wv;
   if (wave >= nwaves) return;
@@ -333,14 +334,19 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
       // all 16 bytes kept: one unaligned 16-byte LDS store (gfx950 takes unaligned DS accesses) instead of 16 byte stores
       __builtin_memcpy(lds + at, &v, 16);
 #endif
-    } else {
+    } else if (out) {
+      // Some bytes dropped (a line end, a header): 16 byte stores without a branch -- a kept byte goes to the running
+      // position, a dropped one to the lane's dump word (a branch per byte cost twice the instructions, and every wave
+      // of a read file holds such lanes).  Separators are then written over the '>' bytes they stand for.
+      const unsigned dump = FP_WAVE_BYTES + 32 + 64 + ((unsigned)lane << 2);
+      unsigned a = at;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if ((out >> j) & 1u) {
-          lds[at] = ((sep >> j) & 1u) ? (uint8_t)MK_SEP : FP_BYTE(j);
-          ++at;
-        }
+        const unsigned kept = (out >> j) & 1u;
+        lds[kept ? a : dump] = FP_BYTE(j);
+        a += kept;
       }
+      for (unsigned sp = sep; sp; sp &= sp - 1) lds[at + __popc(out & ((1u << (__ffs(sp) - 1)) - 1u))] = (uint8_t)MK_SEP;
     }
 #undef FP_BYTE
     filled += __shfl(inc, 63);
@@ -369,11 +375,12 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
       const u64 s_lo = b << 6, s_hi = s_lo + 64;
       const u64 lo = s_lo > g0 ? s_lo : g0, hi = s_hi < g1 ? s_hi : g1;
       u64 w0 = 0, w1 = 0, bd = 0;
+      unsigned b8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
       // always the 64-byte vector path, four characters per 32-bit operation:
       //   code      = ((ch >> 1) & 3) ^ ((ch >> 2) & 1)      A 0, C 1, G 2, T 3 (any other byte: something in 0..3)
       //   expected  = "ACGT"[code]   (one v_perm_b32 with the codes as byte selectors)
       //   bad       = expected != ch (non-zero byte test), its code cleared
-      //   8 bits of codes, first character on top = (codes * 0x40100401) >> 24
+      //   8 bits of codes, first character on top: a dot product with the weights 64, 16, 4, 1
       const uint4* p = reinterpret_cast<const uint4*>(lds + (long)shift + (long)(s_lo - g0));  // 16-byte aligned
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -383,14 +390,18 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
           const unsigned xd = d == 0 ? v.x : (d == 1 ? v.y : (d == 2 ? v.z : v.w));
           const unsigned c = ((xd >> 1) & 0x03030303u) ^ ((xd >> 2) & 0x01010101u);
           const unsigned df = __builtin_amdgcn_perm(0u, 0x54474341u, c) ^ xd;
-          const unsigned nz = ((((df & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | df) >> 7) & 0x01010101u;  // 1 in every bad byte
-          const unsigned g = ((c & ~(nz | (nz << 1))) * 0x40100401u) >> 24;
-          const unsigned b4 = (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;  // character e of the four -> bit e
+          const unsigned nz = (((df & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | df) & 0x80808080u;  // 0x80 in every bad byte
+          const unsigned m1 = nz >> 7;
+          const unsigned ck = c & ~(m1 | (m1 << 1));                                     // (a bad character's code is 0)
+          // v_dot4_u32_u8 as the gather: four codes -> one byte (first character on top), four flags -> one nibble
+          const unsigned g = __builtin_amdgcn_udot4(ck, 0x01041040u, 0u, false);
           const int idx = q * 4 + d;  // characters 4 idx .. 4 idx + 3 of the word
           if (idx < 8) w0 |= (u64)g << (56 - 8 * idx); else w1 |= (u64)g << (56 - 8 * (idx - 8));
-          bd |= (u64)b4 << (4 * idx);
+          b8[idx >> 1] = __builtin_amdgcn_udot4(nz, (idx & 1) ? 0x80402010u : 0x08040201u, b8[idx >> 1], false);  // 128 x flags
         }
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bd |= (u64)(b8[i] >> 7) << (8 * i);
       if (hi - lo == 64) {
         codes[2 * b] = w0;
         codes[2 * b + 1] = w1;
