@@ -792,7 +792,10 @@ def test_equal_chunks_inherit_bucket_regions(monkeypatch):
             assert got == want, (k, c, env)
         assert seen["1"]["part_reused"] == 0
         assert seen[""]["part_reused"] >= 2, seen[""]
-        assert seen[""]["part_retries"] >= 1, seen[""]     # the repeat array did not fit the reads' regions
+        if not os.environ.get("MK_NO_SPECULATION"):
+            # (the one-read-back lane compares raw lengths; the general lane compares sequence lengths, and the repeat
+            # array's single header makes its sequence 6 % longer: it sizes its own regions there)
+            assert seen[""]["part_retries"] >= 1, seen[""]     # the repeat array did not fit the reads' regions
 
 
 @pytest.mark.parametrize("qcap", ["0", "300", None])
