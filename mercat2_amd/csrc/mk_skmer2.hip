@@ -33,8 +33,12 @@
 #define SK2C_WAVES (SK2C_THREADS / 64)
 #define SK2C_QCAP 128     // deferred keys a wave can hold: < 64 left over + one slot x 64 lanes pushed at once
 #define SK2C_THREADS 1024
+#ifndef SK2C_TARGET
 #define SK2C_TARGET (SK2C_SLOTS * 6 / 10)
+#endif
+#ifndef SK2C_LOADCAP
 #define SK2C_LOADCAP (SK2C_SLOTS * 3 / 4)
+#endif
 #define SK2C_SUB_BITS 16
 #define SK2C_MAX_PROBE 64
 #define SK2C_LOCK 0x80000000u
