@@ -818,6 +818,22 @@ def test_scatter_queue_and_walk_agree(monkeypatch, qcap):
         assert got == want, (k, c, canon, qcap)
 
 
+@pytest.mark.parametrize("nkmax", ["1", "3", "5", "12", "31"])
+def test_record_length_limit_is_only_a_layout_choice(monkeypatch, nkmax):
+    """Runs of windows that share a minimizer are cut into records of at most 8 windows (MK_NKMAX moves the limit:
+    the histogram cuts them while it walks, the scatter with mask arithmetic beforehand -- both must cut alike or the
+    bucket sizes would not match what is written).  Any limit gives the same table."""
+    from oracle import c_oracle
+    monkeypatch.setenv("MK_NKMAX", nkmax)
+    monkeypatch.setenv("MK_SAMPLE_MIN", "0")
+    data = native.synth_reads(200_000, 9, 50_000, 150, 10).tobytes() + b">t\n" + b"ACGTTGCAAG" * 3000 + b"\n>p\n" + b"C" * 9000 + b"\n"
+    for k, c in ((21, 2), (31, 1), (32, 1), (18, 3)):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, c)
+            got = ctx.to_dict()
+        assert got == c_oracle.count_dict(data, k, c), (k, c, nkmax)
+
+
 def test_skewed_genome_like_input_at_scale_vs_c_oracle():
     """60 MB that look like an assembly rather than reads: megabase single-line records, a satellite
     array (171-bp unit, 1 % mutated copies), poly-A, a dinucleotide repeat and N gaps next to random
