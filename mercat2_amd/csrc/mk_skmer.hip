@@ -688,11 +688,16 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               unsigned live = 0;  // bit u: slot u holds a key of this pass
               // every key's compare-and-swap is issued as soon as its slot is known, so that the hashing of the
               // later keys runs while the earlier ones are on their way through the LDS
+              // canonical keys: the reverse complement ROLLS with the window -- the base that enters the key on the
+              // right enters its reverse complement, complemented, on the left -- one full reversal per 8 keys
+              u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
 #pragma unroll
               for (int u = 0; u < SKC_B; ++u) {
-                kk[u] = mk_canon2(x >> kshift, k, CANON);
+                const u64 fw = x >> kshift;
+                kk[u] = (CANON && rcv < fw) ? rcv : fw;
                 x = (x << 2) | (y >> 62);
                 y <<= 2;
+                if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
                 hh[u] = skc_hash(kk[u]);
                 bool on = base + u < nk;
                 if (K32 && on && kk[u] == MK_EMPTY) {
