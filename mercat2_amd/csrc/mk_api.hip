@@ -420,7 +420,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     rc = two ? mk_launch_import128_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_keys2.p,
                                            (const uint64_t*)c->surv_cnts.p, meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1)
              : mk_launch_import_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p,
-                                        meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+                                        meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1, (size_t)h->survivors);
     mk_prof_end(c);
     if (rc) return rc;
   }
@@ -581,7 +581,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
       const size_t p1 = (size_t)1 << c->p1_log2;
       const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
       rc = mk_launch_import_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p,
-                                    meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1);
+                                    meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1, (size_t)c->h_info->survivors);
     } else {
       rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors);
     }

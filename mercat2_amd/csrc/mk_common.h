@@ -227,7 +227,7 @@ int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot*
 int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
-                             const uint64_t* nsurv, size_t p1);
+                             const uint64_t* nsurv, size_t p1, size_t survivors);
 int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows);
 // two-word keys (mk_table.hip): survivors {hi, lo, count} per bucket region / rows {hi, lo} interleaved -> run128
 int mk_launch_import128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts, const uint64_t* kstart,

@@ -113,11 +113,14 @@ __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __r
 }
 
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
-                             const uint64_t* nsurv, size_t p1) {
+                             const uint64_t* nsurv, size_t p1, size_t survivors) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   // (few workgroups, each wave walking several buckets: every workgroup ends with one add to the same counter, and
   // adds to one address are serialised by the L2 at ~4 ns each)
-  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, 512)), dim3(256), 0, c->stream, (const u64*)d_keys,
+  // Many survivors per bucket (-c 1, canonical keys: a bucket keeps a thousand keys, each upsert is two dependent
+  // round trips to HBM): every bucket gets its own wave at once -- the kernel is bound by requests in flight.
+  const unsigned cap = survivors > 64 * p1 ? 4096u : 512u;
+  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, cap)), dim3(256), 0, c->stream, (const u64*)d_keys,
                      (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
                      (u64)(c->run_slots - 1), &info->new_rows);
   MK_HIP(hipGetLastError());
