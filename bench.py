@@ -363,6 +363,26 @@ def main():
             # (not `achieved`: that one is measured inside the timed region, where two contexts share the GPU)
             line["roofline"]["one_context"] = {"ms_per_launch": solo_ms, "achieved": solo_ach, "frac": solo_ach / HBM_PEAK_GBS,
                                                "note": "same kernel, untimed extra pass with one context"}
+        if rank == 0:
+            # the box's own stream-copy rate beside the nominal peak (1 GiB device-to-device copy, read + write
+            # bytes / time, best of 5, after the timed region)
+            try:
+                src = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+                dst = torch.empty_like(src)
+                best = None
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    dst.copy_(src)
+                    e1.record()
+                    e1.synchronize()
+                    ms = e0.elapsed_time(e1)
+                    best = ms if best is None or ms < best else best
+                line["roofline"]["measured_stream_copy"] = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
+                line["roofline"]["frac_of_measured_copy"] = achieved / line["roofline"]["measured_stream_copy"]
+                del src, dst
+            except Exception as e:  # (a probe, not the product: never fail the bench line over it)
+                line["roofline"]["measured_stream_copy"] = None
         if world == 1 and not args.no_file_leg:
             line["file_to_tsv"] = file_to_tsv_leg(args, k, canonical)
         if not args.no_cpu and world == 1:
