@@ -63,14 +63,41 @@ def cpu_sample_worker(args):
     return reads * READ_LEN, time.perf_counter() - t0, len(table)
 
 
-def cpu_baseline(k, c, genome, gseed, rseed, chunk_reads):
+def host_cores():
+    """(logical CPUs this process may run on, physical cores among them, CPU quota of the cgroup or None)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    seen = set()
+    for cpu in allowed:
+        try:
+            sib = Path("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu).read_text().strip()
+        except OSError:
+            sib = str(cpu)
+        seen.add(sib)
+    quota = None
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return len(allowed), max(1, len(seen)), quota
+
+
+def cpu_baseline(k, c, genome, gseed, rseed, chunk_reads, want_cores=0):
     """Bounded CPU run of the oracle on the benchmark's own reads: the first chunk of the sample
-    (chunk_reads reads) is split into P equal slices, one per process; every process counts its slice
+    (chunk_reads reads) is split into slices, one per process at a time; every process counts its slice
     as find_kmers would (dict of strings, per-file filter).  The slices' dicts (~4.5 M keys each at
     S2) are far out of cache, as the real chunk's 20 M keys are; smaller dicts are, if anything, kind
-    to the CPU."""
+    to the CPU.  P = the physical cores this process may use, capped by the
+    cgroup's CPU quota when there is one; --cpu-cores overrides."""
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    logical, physical, quota = host_cores()
+    cores = physical if quota is None else max(1, min(physical, int(quota + 0.5)))
+    if want_cores > 0:
+        cores = want_cores
     per = max(1000, chunk_reads // 16)  # the same slice size whatever the core count (~0.5 GB of dict per process at S2)
     rounds = 3                          # slices per process, one after the other: ~10-30 s of CPU work per core
     jobs = [(genome, gseed, rseed, i * per, per, k, c) for i in range(cores * rounds)]
@@ -80,7 +107,8 @@ def cpu_baseline(k, c, genome, gseed, rseed, chunk_reads):
     wall = time.perf_counter() - t0
     bases = sum(r[0] for r in res)
     busy = sum(r[1] for r in res)
-    out = {"value": bases / wall, "unit": "bases/s", "cores": cores, "kind": "port",
+    out = {"value": bases / wall, "unit": "bases/s", "cores": cores, "cores_available": logical, "physical_cores": physical,
+           "cpu_quota": quota, "kind": "port",
            "sample": "reads 0..%d of the benchmark sample (genome %d bp, seeds %d/%d: the head of its first %d-read chunk), "
                      "%d slices of %d reads x %d bp, %d processes, k=%d, c=%d, pure-Python oracle (oracle/cpu_ref.py); "
                      "per-core rate %.3g bases/s"
@@ -101,27 +129,61 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, timeout_s):
     """Start n copies of this script, one per GPU, and relay rank 0's line.  This (parent) process
-    never touches the GPU and execs nothing: the children are fresh processes."""
+    never touches the GPU and execs nothing: the children are fresh processes.  A watchdog ends the run
+    when the ranks have not finished after timeout_s seconds (a rank stuck in RCCL init or in a collective
+    would otherwise hang until the driver kills the job): the children are killed and the last lines each
+    rank wrote to stderr are shown."""
+    import tempfile
+    import threading
     port = free_port()
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), MK_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        log = tempfile.TemporaryFile(mode="w+b")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=log))
+    timed_out = threading.Event()
+
+    def watchdog():
+        deadline = time.monotonic() + timeout_s
+        while time.monotonic() < deadline:
+            if all(p.poll() is not None for p in procs):
+                return
+            time.sleep(0.5)
+        timed_out.set()
+        for p in procs:  # exactly the children started above, by handle
+            if p.poll() is None:
+                p.kill()
+
+    wd = threading.Thread(target=watchdog, daemon=True)
+    wd.start()
     out, _ = procs[0].communicate()
     rcs = [p.wait() for p in procs]
+    wd.join()
+
+    def tail(log, lines=15):
+        log.seek(0)
+        return b"\n".join(log.read().splitlines()[-lines:]).decode(errors="replace")
     # exactly one line on stdout: rank 0's JSON (whatever else a library printed there goes to stderr)
-    lines = out.decode().splitlines()
-    for ln in lines:
+    for ln in out.decode().splitlines():
         (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc]
-    if bad:
+    if timed_out.is_set() or bad:
+        for r, log in enumerate(logs):
+            sys.stderr.write("---- rank %d (exit %s), last lines of stderr:\n%s\n" % (r, rcs[r], tail(log)))
+        if timed_out.is_set():
+            raise SystemExit("bench.py: the ranks did not finish within --rank-timeout %d s; killed" % timeout_s)
         raise SystemExit("bench.py: rank(s) failed: %s" % bad)
+    for r, log in enumerate(logs):  # (warnings of a good run still reach the terminal)
+        text = tail(log, 5)
+        if text.strip():
+            sys.stderr.write("[rank %d] %s\n" % (r, text))
 
 
 # ----------------------------------------------------------------------------------- one rank
@@ -138,6 +200,13 @@ def main():
     ap.add_argument("--genome-seed", type=int, default=GENOME_SEED)
     ap.add_argument("--read-seed", type=int, default=READ_SEED)
     ap.add_argument("--sub-ppm", type=int, default=0, help="per-base substitution rate, parts per million (S2e: 10000)")
+    ap.add_argument("--rank-timeout", type=int, default=900,
+                    help="self-launched ranks (--gpus N without a launcher): seconds after which they are killed and their stderr shown")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N driven by THIS one process through the C ABI (mk_merge_devices: peer copies over xGMI) "
+                         "instead of one process per GPU over RCCL")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the cpu_baseline leg (default: the physical cores available)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configs after the main region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-file-leg", action="store_true", help="skip the file-to-TSV leg")
     ap.add_argument("--no-also", action="store_true", help="N > 1: do not time the other scaling mode after the main region")
@@ -151,13 +220,20 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if "RANK" not in os.environ and args.gpus > 1:
+    single = bool(args.single_process) and args.gpus > 1
+    if "RANK" not in os.environ and args.gpus > 1 and not single:
         # no launcher: be one (before torch.cuda / HIP is touched in this process)
-        return launch_ranks(args.gpus, sys.argv[1:])
+        return launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if os.environ.get("MK_BENCH_TEST_HANG") == str(rank) and os.environ.get("MK_BENCH_CHILD"):
+        sys.stderr.write("rank %d: (test) pretending to hang before touching the GPU\n" % rank)
+        sys.stderr.flush()
+        time.sleep(3600)  # tests/test_bench_launcher.py: the launcher's watchdog must end this
+    if single and world != 1:
+        raise SystemExit("--single-process is one process for all GPUs: do not start it under a launcher")
+    if not single and world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
 
     import numpy as np
@@ -168,9 +244,17 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     backend = os.environ.get("MK_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a 1-GPU box
     ndev = torch.cuda.device_count()
-    if backend == "nccl" and world > ndev:
-        raise SystemExit("%d ranks but %d GPU(s): RCCL needs one device per rank (MK_BENCH_BACKEND=gloo rehearses on fewer)" % (world, ndev))
-    local = local % ndev
+    if single:
+        # MK_BENCH_SHARE_DEVICE=1: rehearsal on a one-GPU box, every "GPU" is device 0 (contexts side by side)
+        share = bool(os.environ.get("MK_BENCH_SHARE_DEVICE"))
+        if args.gpus > ndev and not share:
+            raise SystemExit("%d GPUs asked for, %d visible (MK_BENCH_SHARE_DEVICE=1 rehearses on fewer)" % (args.gpus, ndev))
+        devices = [i % ndev for i in range(args.gpus)] if share else list(range(args.gpus))
+    else:
+        if backend == "nccl" and world > ndev:
+            raise SystemExit("%d ranks but %d GPU(s): RCCL needs one device per rank (MK_BENCH_BACKEND=gloo rehearses on fewer)" % (world, ndev))
+        devices = [local % ndev]
+    local = devices[0]
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -189,65 +273,105 @@ def main():
     k = args.k
     canonical = bool(args.canonical)
     nctx = args.contexts if args.contexts > 0 else native.default_streams(k, native.ALPHABET_NT2)
-    ctxs = [native.Counter(k, native.ALPHABET_NT2, device=local, canonical=canonical) for _ in range(nctx)]
-    ctx = ctxs[0]
-    pool = ThreadPoolExecutor(nctx) if nctx > 1 else None
-    key_bits = 2 * k
-    out_cap = (2 * args.genome + 1024) * (1 if args.sub_ppm == 0 else 12)  # distinct forward-strand k-mers of both strands, upper bound
-    words = ctx.words_per_key()
-    out_keys = torch.empty(out_cap * words, dtype=torch.int64, device=dev)
-    out_cnts = torch.empty(out_cap, dtype=torch.int64, device=dev)
+    ngpu = len(devices) * world  # GPUs of the whole job
+    part = rank if world > 1 else None  # which share of the job this process has (one GPU per rank, or all of them)
+
+    class Engine:
+        """The contexts of this process for one (k, canonical): nctx per device it drives."""
+
+        def __init__(self, k, canonical, genome, sub_ppm):
+            self.k, self.canonical = k, canonical
+            self.by_dev = [[native.Counter(k, native.ALPHABET_NT2, device=d, canonical=canonical) for _ in range(nctx)] for d in devices]
+            self.leaders = [c[0] for c in self.by_dev]
+            self.all = [c for cs in self.by_dev for c in cs]
+            self.pool = ThreadPoolExecutor(len(self.all)) if len(self.all) > 1 else None
+            self.words = self.leaders[0].words_per_key()
+            self.key_bits = 2 * k
+            cap = (2 * genome + 1024) * (1 if sub_ppm == 0 else 12)  # distinct forward-strand k-mers of both strands, upper bound
+            self.out_cap = cap
+            self.out = [(torch.empty(cap * self.words, dtype=torch.int64, device="cuda:%d" % d),
+                         torch.empty(cap, dtype=torch.int64, device="cuda:%d" % d)) for d in devices]
+            self.merge_stats = None
+
+        def close(self):
+            if self.pool:
+                self.pool.shutdown()
+            for c in self.all:
+                c.close()
+
+        def make_step(self, parts_by_dev):
+            jobs = []  # (context, its chunks)
+            for di, cs in enumerate(self.by_dev):
+                ptrs = [(p.data_ptr(), p.numel()) for p in parts_by_dev[di]]
+                for i, c in enumerate(cs):
+                    jobs.append((c, ptrs[i::nctx]))
+
+            def count_share(job):
+                c, mine = job
+                c.reset()
+                for ptr, n in mine:  # every chunk is filtered on its own (the per-chunk -c rule)
+                    c.count_device(ptr, n, MIN_COUNT)
+
+            def finish_device(di):
+                lead = self.leaders[di]
+                for c in self.by_dev[di][1:]:  # sum the other contexts' survivors into the device's first, on the device
+                    lead.merge_from(c)
+
+            def export_device(di):
+                return self.leaders[di].export_pairs_device(self.out[di][0].data_ptr(), self.out[di][1].data_ptr(), self.out_cap)
+
+            def step():
+                if self.pool is None:
+                    count_share(jobs[0])
+                else:
+                    list(self.pool.map(count_share, jobs))
+                if len(devices) == 1:
+                    finish_device(0)
+                else:
+                    list(self.pool.map(finish_device, range(len(devices))))
+                    # one process, several GPUs: key-range ownership, peer copies, import at the owners (mk_multi.hip)
+                    self.merge_stats = native.merge_devices(self.leaders, native.MERGE_RANGES | native.MERGE_BALANCED)
+                if world > 1:
+                    merge_ranks(self.leaders[0], self.key_bits, device=dev)
+                if len(devices) == 1:
+                    return export_device(0)
+                return sum(self.pool.map(export_device, range(len(devices))))  # every owner sorts its own range
+            return step
 
     # ---- synthetic input: generate on the host, cut like the reference Chunker, move to HBM
-    def load_sample(mode):
-        """(device chunk tensors of this rank, chunks of the sample, bases this step counts over all ranks, gen seconds)."""
+    def load_sample(mode, reads, genome, gseed, rseed, sub_ppm):
+        """(device chunk tensors per device of this process, chunks of a sample, bases one step counts over the whole job, gen seconds)."""
         t0 = time.perf_counter()
-        first = rank * args.reads if mode == "weak" else 0
-        host = native.synth_reads(args.genome, args.genome_seed, args.reads, READ_LEN, args.read_seed, args.sub_ppm, first)
-        offs = chunk_offsets(host, CHUNK_MIB * 1024 * 1024) if host.nbytes >= CHUNK_MIB * 1024 * 1024 else [0, host.nbytes]
-        spans = list(zip(offs[:-1], offs[1:]))
-        mine = spans if mode == "weak" else spans[rank::world]
-        if mode == "weak":
-            whole = torch.from_numpy(host).to(dev)
-            parts = [whole[a:b] for a, b in mine]
-        else:
-            parts = [torch.from_numpy(host[a:b]).to(dev) for a, b in mine]
-        torch.cuda.synchronize()
-        del host
-        total = args.reads * READ_LEN * (world if mode == "weak" else 1)
-        return parts, len(spans), total, time.perf_counter() - t0
-
-    def make_step(parts):
-        ptrs = [(p.data_ptr(), p.numel()) for p in parts]
-
-        def count_share(i):
-            c = ctxs[i]
-            c.reset()
-            for ptr, n in ptrs[i::nctx]:  # every chunk is filtered on its own (the per-chunk -c rule)
-                c.count_device(ptr, n, MIN_COUNT)
-
-        def step():
-            if pool is None:
-                count_share(0)
+        parts_by_dev, nchunks = [], 0
+        for di, d in enumerate(devices):
+            g = (rank if world > 1 else di)  # index of this GPU in the job
+            if mode == "weak" or di == 0:
+                first = g * reads if mode == "weak" else 0
+                host = native.synth_reads(genome, gseed, reads, READ_LEN, rseed, sub_ppm, first)
+                offs = chunk_offsets(host, CHUNK_MIB * 1024 * 1024) if host.nbytes >= CHUNK_MIB * 1024 * 1024 else [0, host.nbytes]
+                spans = list(zip(offs[:-1], offs[1:]))
+                nchunks = len(spans)
+            if mode == "weak":
+                whole = torch.from_numpy(host).to("cuda:%d" % d)
+                parts_by_dev.append([whole[a:b] for a, b in spans])
             else:
-                list(pool.map(count_share, range(nctx)))
-                for c in ctxs[1:]:  # sum the other contexts' survivors into context 0, on the device
-                    ctx.merge_from(c)
-            if world > 1:
-                merge_ranks(ctx, key_bits, device=dev)
-            return ctx.export_pairs_device(out_keys.data_ptr(), out_cnts.data_ptr(), out_cap)
-        return step
+                parts_by_dev.append([torch.from_numpy(host[a:b]).to("cuda:%d" % d) for a, b in spans[g::ngpu]])
+        for d in devices:
+            torch.cuda.synchronize(d)
+        total = reads * READ_LEN * (ngpu if mode == "weak" else 1)
+        return parts_by_dev, nchunks, total, time.perf_counter() - t0
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        for d in devices:
+            torch.cuda.synchronize(d)
 
-    def timed(step, steps, warmup, profile):
+    def timed(eng, step, steps, warmup, profile):
         for _ in range(warmup):
             step()
         if profile:
-            for c in ctxs:
+            for c in eng.all:
                 c.reset_stats()
                 c.set_profiling(True)
         fence()
@@ -264,42 +388,104 @@ def main():
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
         return float(t.item()), int(r[0].item()), int(r[1].item())
 
-    mode = args.scaling if world > 1 else "weak"
-    parts, nchunks, total_bases, gen_s = load_sample(mode)
-    step = make_step(parts)
-    dt, total_rows, ranks_seen = timed(step, args.steps, args.warmup, True)
-    stats = [c.stats() for c in ctxs]
-    for c in ctxs:
+    def sum_stats(ctx_list):
+        stats = [c.stats() for c in ctx_list]
+        st = dict(stats[0])
+        for other in stats[1:]:
+            for key, val in other.items():
+                if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct",
+                                                              "part_retries", "part_reused"):
+                    st[key] += val
+        return st
+
+    # the reference's table of this exact workload (tests/golden/expected_s2.json, made by tests/golden/make_s2_golden.py)
+    golden_rows = {}
+    try:
+        gj = json.loads((ROOT / "tests" / "golden" / "expected_s2.json").read_text())["S2|k31|c10|s100"]
+        golden_rows = {False: gj["forward"]["rows"], True: gj["canonical"]["rows"]}
+    except (OSError, KeyError, ValueError):
+        pass
+
+    def verify_rows(rows, mode, reads, genome, kk, sub_ppm, canon, gseed, rseed):
+        """True/False when this run is the S2 sample whose table the reference produced; None when it is another workload."""
+        is_ref = (reads, genome, kk, sub_ppm, gseed, rseed) == (READS, GENOME, K, 0, GENOME_SEED, READ_SEED) and (ngpu == 1 or mode == "strong")
+        if not is_ref or canon not in golden_rows:
+            return None
+        return rows == golden_rows[canon]
+
+    mode = args.scaling if ngpu > 1 else "weak"
+    eng = Engine(k, canonical, args.genome, args.sub_ppm)
+    parts, nchunks, total_bases, gen_s = load_sample(mode, args.reads, args.genome, args.genome_seed, args.read_seed, args.sub_ppm)
+    step = eng.make_step(parts)
+    dt, total_rows, ranks_seen = timed(eng, step, args.steps, args.warmup, True)
+    st = sum_stats(eng.all)
+    for c in eng.all:
         c.set_profiling(False)
-    st = dict(stats[0])
-    for other in stats[1:]:  # totals over the contexts of this GPU
-        for key, val in other.items():
-            if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct"):
-                st[key] += val
+    verified = verify_rows(total_rows, mode, args.reads, args.genome, k, args.sub_ppm, canonical, args.genome_seed, args.read_seed)
 
     # After the timed region: the same kernels alone on the GPU (one context, one pass), so that the
     # dominant kernel's duration can also be read without the other stream's kernels on its CUs.
     solo = None
     if nctx > 1 and rank == 0:
-        c = ctxs[0]
+        c = eng.all[0]
         c.reset()
         c.reset_stats()
         c.set_profiling(True)
-        for p in parts:
+        for p in parts[0]:
             c.count_device(p.data_ptr(), p.numel(), MIN_COUNT)
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(devices[0])
         solo = c.stats()
         c.set_profiling(False)
 
     # the other scaling mode, timed after the main region (N > 1 only)
     also = None
-    if world > 1 and not args.no_also:
+    if ngpu > 1 and not args.no_also:
         other_mode = "strong" if mode == "weak" else "weak"
-        parts2, nchunks2, total2, _ = load_sample(other_mode)
-        dt2, rows2, _ = timed(make_step(parts2), args.steps, 1, False)
+        del parts
+        parts2, nchunks2, total2, _ = load_sample(other_mode, args.reads, args.genome, args.genome_seed, args.read_seed, args.sub_ppm)
+        dt2, rows2, _ = timed(eng, eng.make_step(parts2), args.steps, 1, False)
+        v2 = verify_rows(rows2, other_mode, args.reads, args.genome, k, args.sub_ppm, canonical, args.genome_seed, args.read_seed)
         also = {"scaling": other_mode, "value": total2 * args.steps / dt2, "unit": "bases/s", "ms_per_step": dt2 / args.steps * 1e3,
-                "rows": rows2, "chunks": nchunks2, "note": "timed after the main region, same steps, 1 warm-up"}
+                "rows": rows2, "verified_rows": v2, "chunks": nchunks2, "note": "timed after the main region, same steps, 1 warm-up"}
+        if v2 is False:
+            verified = False
         del parts2
+        parts = None
+
+    # the other BASELINE configs, each a short run after the main region (one GPU, default workload only):
+    # config 3 as worded (canonical keys), config 2 (S1: 1 M reads, k=21) and config 5 (S3: 50 M reads, k=63)
+    configs = None
+    default_run = (args.reads, args.genome, k, args.sub_ppm, canonical) == (READS, GENOME, K, 0, False)
+    if ngpu == 1 and rank == 0 and default_run and not args.no_configs:
+        configs = {}
+
+        def short_run(name, kk, canon, reads, genome, gseed, rseed, steps, parts_in=None):
+            e2 = Engine(kk, canon, genome, 0)
+            try:
+                p2, nch, tot, _ = (parts_in, nchunks, total_bases, 0) if parts_in is not None else load_sample("weak", reads, genome, gseed, rseed, 0)
+                d2, rows2, _ = timed(e2, e2.make_step(p2), steps, 1, True)
+                s2 = sum_stats(e2.all)
+                two = s2["mode_name"] == "hash128"
+                bpw = 24 if two else 16
+                ms_l = s2["ms_count"] / max(1, s2["n_count"])
+                ach = (s2["windows"] - s2["exotic_windows"]) * bpw / max(1, s2["n_count"]) / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
+                configs[name] = {"value": tot * steps / d2, "unit": "bases/s", "ms_per_step": d2 / steps * 1e3, "steps": steps, "warmup": 1,
+                                 "rows": rows2, "chunks": nch, "k": kk, "reads": reads, "genome": genome, "canonical": canon,
+                                 "mode": s2["mode_name"], "count_kernel_ms_per_launch": ms_l, "count_kernel_frac": ach / HBM_PEAK_GBS,
+                                 "bytes_per_window": bpw,
+                                 "verified_rows": verify_rows(rows2, "weak", reads, genome, kk, 0, canon, gseed, rseed)}
+                del p2
+            finally:
+                e2.close()
+
+        short_run("config3_canonical", K, True, READS, GENOME, GENOME_SEED, READ_SEED, max(2, args.steps // 4), parts_in=parts)
+        if configs["config3_canonical"]["verified_rows"] is False:
+            verified = False
+        del parts
+        parts = None
+        torch.cuda.empty_cache()
+        short_run("config2_s1_k21", 21, False, 1_000_000, 1_000_000, 1, 2, max(2, args.steps))
+        short_run("config5_s3_k63", 63, False, 50_000_000, 50_000_000, 6, 7, 2)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -321,7 +507,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate rocprofv3 runs of this command, gfx950 correction applied: tools/trim_profiles.py)
         traffic, traffic_src = None, None
-        for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
             pmc_file = ROOT / "profiles" / name
             if pmc_file.exists() and args.reads == READS and k == K and not canonical:
                 pmc = json.loads(pmc_file.read_text())
@@ -330,22 +516,30 @@ def main():
                     traffic_src = "profiles/" + name.replace(".json", ".csv")
                     break
         is_s2 = (args.reads, args.genome, k, args.sub_ppm) == (READS, GENOME, K, 0)
+        if single:
+            par = "one process, %d GPUs: chunks->GPUs, key-range merge by peer copies (mk_merge_devices)" % ngpu
+        elif world > 1:
+            par = "chunks->ranks, key-range all-to-all merge"
+        else:
+            par = "1 GPU"
         line = {
-            "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": world,
+            "metric": "bases/sec at k=31, 10Mx150bp", "value": value, "unit": "bases/s", "n_gpus": ngpu,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": mode, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "ranks_seen": ranks_seen, "rccl": bool(world > 1 and backend == "nccl"), "backend": backend if world > 1 else None,
+            "single_process": single,
             "config": {"workload": "%s: %d reads x %d bp %s from a %d bp genome, k=%d, -c %d, -s %d (%d chunks per sample), %s keys"
                                    % ("S2" if is_s2 else "custom", args.reads, READ_LEN,
                                       "per GPU" if mode == "weak" else "in all (one sample, chunks dealt i mod N)", args.genome, k,
                                       MIN_COUNT, CHUNK_MIB, nchunks, "canonical" if canonical else "forward-strand"),
-                       "reads_per_gpu": args.reads if mode == "weak" else args.reads / world, "read_len": READ_LEN, "k": k,
+                       "reads_per_gpu": args.reads if mode == "weak" else args.reads / ngpu, "read_len": READ_LEN, "k": k,
                        "min_count": MIN_COUNT, "chunk_mib": CHUNK_MIB, "chunks": nchunks, "mode": st["mode_name"],
-                       "contexts_per_gpu": nctx,
-                       "parallelism": "chunks->ranks, key-range all-to-all merge" if world > 1 else "1 GPU"},
+                       "contexts_per_gpu": nctx, "parallelism": par},
             "distinct_kmers_per_s": total_rows * args.steps / dt,
             "distinct_prefilter_per_s": st["distinct"] * world / dt,  # distinct keys per chunk, before the -c filter
             "rows": total_rows,
+            # the rows the REFERENCE gets for this sample (tests/golden/expected_s2.json); null when the run is not that sample
+            "verified_rows": verified,
             "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "part", "count", "exotic", "filter", "export")},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -355,39 +549,42 @@ def main():
                          "stage_frac": stage_achieved / HBM_PEAK_GBS},
             "input_gen_s": gen_s,
         }
+        if eng.merge_stats:
+            line["merge_devices"] = eng.merge_stats
         if also:
             line["also"] = also
+        if configs:
+            line["configs"] = configs
         if solo and solo["n_count"] and solo["ms_count"] > 0:
             solo_ms = solo["ms_count"] / solo["n_count"]
             solo_ach = (solo["windows"] - solo["exotic_windows"]) * bytes_per_window / solo["n_count"] / (solo_ms * 1e-3) / 1e9
             # (not `achieved`: that one is measured inside the timed region, where two contexts share the GPU)
             line["roofline"]["one_context"] = {"ms_per_launch": solo_ms, "achieved": solo_ach, "frac": solo_ach / HBM_PEAK_GBS,
                                                "note": "same kernel, untimed extra pass with one context"}
-        if rank == 0:
-            # the box's own stream-copy rate beside the nominal peak (1 GiB device-to-device copy, read + write
-            # bytes / time, best of 5, after the timed region)
-            try:
-                src = torch.empty(1 << 28, dtype=torch.int32, device=dev)
-                dst = torch.empty_like(src)
-                best = None
-                for _ in range(5):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    dst.copy_(src)
-                    e1.record()
-                    e1.synchronize()
-                    ms = e0.elapsed_time(e1)
-                    best = ms if best is None or ms < best else best
-                line["roofline"]["measured_stream_copy"] = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
-                line["roofline"]["frac_of_measured_copy"] = achieved / line["roofline"]["measured_stream_copy"]
-                del src, dst
-            except Exception as e:  # (a probe, not the product: never fail the bench line over it)
-                line["roofline"]["measured_stream_copy"] = None
-        if world == 1 and not args.no_file_leg:
+        # the box's own stream-copy rate beside the nominal peak (1 GiB device-to-device copy, read + write
+        # bytes / time, best of 5, after the timed region)
+        try:
+            src = torch.empty(1 << 28, dtype=torch.int32, device=dev)
+            dst = torch.empty_like(src)
+            best = None
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dst.copy_(src)
+                e1.record()
+                e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                best = ms if best is None or ms < best else best
+            line["roofline"]["measured_stream_copy"] = 2 * src.numel() * 4 / (best * 1e-3) / 1e9
+            line["roofline"]["frac_of_measured_copy"] = achieved / line["roofline"]["measured_stream_copy"]
+            del src, dst
+        except Exception:  # (a probe, not the product: never fail the bench line over it)
+            line["roofline"]["measured_stream_copy"] = None
+        if ngpu == 1 and not args.no_file_leg:
             line["file_to_tsv"] = file_to_tsv_leg(args, k, canonical)
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and ngpu == 1:
             chunk_reads = max(1, args.reads // max(1, nchunks))
-            line["cpu_baseline"] = cpu_baseline(k, MIN_COUNT, args.genome, args.genome_seed, args.read_seed, chunk_reads)
+            line["cpu_baseline"] = cpu_baseline(k, MIN_COUNT, args.genome, args.genome_seed, args.read_seed, chunk_reads, args.cpu_cores)
             line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             if "file_to_tsv" in line:  # the target is stated on the file-to-TSV window
                 cpu = line["cpu_baseline"]["value"]
@@ -397,11 +594,13 @@ def main():
                                                       "CPU run that also had to inflate the .gz the ratio would be larger")
         print(json.dumps(line))
         sys.stdout.flush()
-    for c in ctxs:
-        c.close()
+    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if verified is False:
+        raise SystemExit("bench.py: the table of the timed workload has %d rows, the reference's table of the same sample has %s: "
+                         "the result is WRONG" % (total_rows, golden_rows.get(canonical)))
 
 
 def file_to_tsv_leg(args, k, canonical):

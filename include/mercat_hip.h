@@ -74,6 +74,9 @@ typedef struct mk_stats_t {
 /* One context per GPU and per (alphabet, k).  Replaces the per-task state of
  * countKmers/find_kmers (bin/mercat2.py:112-114). */
 int mk_create(int device, int alphabet, int k, mk_ctx** out);
+/* HIP devices this process sees (0 when there is none or the runtime cannot start): the GPUs a host may spread a
+ * sample's chunks over, or give one small sample each (bin/mercat2.py:217 sizes its Ray pool by -n the same way). */
+int mk_device_count(void);
 void mk_destroy(mk_ctx* ctx);
 const char* mk_last_error(const mk_ctx* ctx);
 /* Forget the running (merged) table: start the next sample (run_mercat2's `kmers = dict()`,
@@ -116,17 +119,25 @@ typedef struct mk_file_stats_t {
   int32_t members;     /* gzip members seen                                                  */
   int32_t threads;     /* reader threads used                                                */
   int32_t contexts;    /* contexts that counted chunks                                       */
+  int32_t devices;     /* GPUs those contexts are on                                         */
+  int32_t split_pieces;/* > 0: the file was one filter unit counted in that many pieces on several GPUs, filtered after the sum */
   int32_t pad_;
   double s_wait_io;    /* seconds the dispatching thread waited for file blocks              */
   double s_wait_gpu;   /* seconds it waited for a context to finish its previous chunk       */
   double s_total;      /* wall seconds of the call                                           */
+  double s_merge;      /* of those, the sum of the contexts' tables at the end                */
 } mk_file_stats_t;
 /* Reads `path` (gzip iff its name ends in ".gz", as the reference decides), splits it as
  * Chunker(path, dest, chunk_bytes, '>') would iff its on-disk size is >= chunk_bytes > 0
  * (chunk_bytes == 0: never), counts every chunk with its own min_count filter and adds the
- * survivors to the running table of ctxs[0].  With nctx > 1 (same device, alphabet, k) the chunks
- * are dealt to the contexts in turn and counted concurrently with the reading; the other
- * contexts' tables are added into ctxs[0] and reset before the call returns.  threads = reader
+ * survivors to the running table of ctxs[0].  With nctx > 1 (same alphabet, k, canonical mode; on one
+ * GPU or on several: mk_plan_contexts gives the order) chunk i goes to ctxs[i mod nctx] and is counted
+ * there, filtered on its own, concurrently with the reading; at the end the contexts of one GPU are summed
+ * on that GPU, the GPUs' tables are summed into ctxs[0] (mk_merge_devices, MK_MERGE_GATHER) and the other
+ * contexts are reset.  A file that is NOT chunked (one filter unit, lib/mercat2_kmers.py:73-76) but large
+ * (>= 64 MiB of text) is, with contexts on several GPUs, cut into one piece per context at record starts
+ * (mk_record_cuts), the pieces are counted unfiltered, summed, and min_count is applied to the sum
+ * (single-chunk sample).  st->split_pieces says so.  threads = reader
  * threads (<= 0: pick): plain files are read, BGZF blocks and -- from 16 MiB on -- ordinary gzip
  * streams are decoded by that many threads; 1 decodes a gzip stream front to back.  st may be NULL. */
 int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, uint64_t chunk_bytes, uint64_t min_count,
@@ -195,6 +206,61 @@ int mk_words_per_key(const mk_ctx* ctx);
  * contexts (= HIP streams) that count concurrently and sum them at the end, on the device. */
 int mk_merge_from(mk_ctx* dst, mk_ctx* src);
 
+/* ---- one process, several GPUs: the Ray fan-out of a sample's chunks over workers and the dict sum of their
+ *      results (bin/mercat2.py:119-127, 336-339) with the workers being the GPUs of one node ------------- */
+/* Equal key ranges: bounds[i-1] = first key (first 64-bit word of the packed key, key_bits wide: bits*k for
+ * one-word keys, 64 for two-word keys) owned by owner i, i = 1..n-1; owner 0 starts at 0.  Host helper. */
+int mk_owner_bounds(int key_bits, int n, uint64_t* bounds);
+/* The order in which to create contexts for ndev devices with `streams` contexts each, so that mk_count_file's
+ * rule "chunk i goes to ctxs[i mod nctx]" sends chunk i to device devices[i mod ndev] and successive
+ * chunks of one device to its different streams: ctx_device[j] = devices[j mod ndev], j < ndev*streams.  Host helper. */
+int mk_plan_contexts(const int* devices, int ndev, int streams, int* ctx_device);
+/* The rows of the running table grouped by owner (owner of a row = number of bounds <= the first word of its
+ * key; n owners, n-1 ascending bounds), written to the DEVICE buffer d_rows as interleaved rows of
+ * mk_words_per_key()+1 words {key word(s), count}, owner after owner; counts[j] (HOST, n values) = rows of owner j.
+ * One pass for the histogram, one for the rows: no sort.  d_rows == NULL: only the counts.  The table is unchanged.
+ * Dense bins travel as {bin, count}; rows kept as text are not included (mk_export_exotic). */
+int mk_bucket_rows_device(mk_ctx* ctx, const uint64_t* bounds, int n, uint64_t* d_rows, size_t cap_rows, uint64_t* counts);
+/* insert-add interleaved rows (that layout) from a DEVICE buffer of this context's GPU into the running table. */
+int mk_import_rows_device(mk_ctx* ctx, const uint64_t* d_rows, size_t rows);
+
+/* About one in `stride` rows of the running table -- the first word of their keys, in no order -- into the HOST
+ * buffer out (cap values; *n = how many): the sample owner bounds with about equal rows per owner are made of
+ * (SURVEY 8e "optionally sampled splitters").  The table is hashed, so every stride-th slot is a uniform sample. */
+int mk_sample_keys(mk_ctx* ctx, size_t stride, uint64_t* out, size_t cap, size_t* n);
+/* Dense mode (k * bits <= 15): the bins as one array of nbins = 4^k / 32^k counts, copied out to (store = 0) or in
+ * from (store != 0) a DEVICE buffer of this context's GPU -- several GPUs sum dense tables with one reduce of that
+ * array instead of exchanging rows. */
+int mk_dense_bins_device(mk_ctx* ctx, uint64_t* d_bins, size_t nbins, int store);
+
+#define MK_MERGE_RANGES 0   /* afterwards ctxs[i] holds exactly the rows of key range i: the concatenation of the
+                               contexts' sorted exports, in order, is the sorted table (mk_*_multi below)        */
+#define MK_MERGE_GATHER 1   /* afterwards ctxs[0] holds every row and the others are empty                        */
+#define MK_MERGE_BALANCED 2 /* (with RANGES) owner bounds from a sample of the keys (about equal rows per owner)
+                               instead of equal key ranges                                                        */
+typedef struct mk_merge_stats_t {
+  uint64_t rows_in;      /* rows of all contexts before the merge (the same key counted once per context) */
+  uint64_t rows_out;     /* rows of all contexts after it (distinct keys)                                  */
+  uint64_t rows_moved;   /* rows copied between different contexts                                          */
+  uint64_t bytes_moved;  /* ... in bytes                                                                    */
+  uint64_t max_owned;    /* rows of the fullest owner afterwards                                            */
+  int32_t contexts, devices;
+  int32_t peer_direct;   /* device pairs with direct peer access (xGMI) among the pairs that exchanged rows */
+  int32_t pad_;
+  double s_bucket, s_copy, s_import, s_total; /* wall seconds of the phases */
+} mk_merge_stats_t;
+/* Sum the running tables of n contexts (same alphabet, k, canonical mode; on n different GPUs, or several on one)
+ * in this one process: every context groups its rows by owner (mk_bucket_rows_device), the segments go straight
+ * to their owners' GPUs (peer copies: each pair of GPUs has its own xGMI link, all pairs at once), every owner
+ * insert-adds what it received.  Rows kept as text end up in ctxs[0].  st may be NULL. */
+int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_stats_t* st);
+/* sorted(kmers.items()) of a table spread over n contexts by key range (after MK_MERGE_RANGES): every context
+ * sorts its own range on its own GPU, at once; the host concatenates in order.  Same outputs as mk_export_size /
+ * mk_export / mk_write_tsv.  MK_ERR_STATE if the contexts' ranges are not ascending and disjoint. */
+int mk_export_size_multi(mk_ctx* const* ctxs, int n, size_t* rows);
+int mk_export_multi(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* counts, size_t rows_cap);
+int mk_write_tsv_multi(mk_ctx* const* ctxs, int n, const char* path, const char* basename, size_t* rows);
+
 /* Drop the rows of the running table whose count is below min_count.  For a sample that is ONE chunk
  * (one filter unit, lib/mercat2_kmers.py:73-76) but was counted in pieces without a filter -- its records
  * split over several GPUs -- and merged: the filter comes after the merge. */
@@ -217,6 +283,11 @@ int mk_chunk_cuts(const uint8_t* text, size_t n, uint64_t chunksize, uint64_t* c
  * misplaced a byte). */
 int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts, size_t cap,
                    size_t* ncuts);
+/* Where mk_count_file cuts ONE filter unit (a file below the chunk size) that it spreads over several GPUs: pieces
+ * of at least `piece` bytes, each ending where a record starts -- a line whose first non-blank byte is '>', what
+ * find_kmers takes for a header (lib/mercat2_kmers.py:51-52); a line that merely contains '>' is not one.
+ * Through the streaming scanner, `block` bytes at a time, self-checked like mk_stream_cuts. */
+int mk_record_cuts(const uint8_t* text, size_t n, uint64_t piece, size_t block, uint64_t* cuts, size_t cap, size_t* ncuts);
 /* The file reader's own gzip decoder (csrc/mk_inflate.h) over a whole '.gz' file held in memory,
  * producing `block` bytes per step as the reader does, every member's CRC-32 and length checked.
  * A self-check for tests (against zlib): out must hold the whole text (cap bytes).

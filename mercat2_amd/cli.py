@@ -49,7 +49,10 @@ def parseargs(argv=None):
     p.add_argument("-pca", action="store_true", help="(MerCat2: PCA plots) accepted, no effect")
     p.add_argument("-debug", action="store_true", help=argparse.SUPPRESS)
     p.add_argument("-category_file", type=str, required=False, help=argparse.SUPPRESS)
-    p.add_argument("-gpu", type=int, default=0, help="HIP device index [0]")
+    p.add_argument("-gpus", type=int, default=None,
+                   help="number of GPUs to use, devices 0..N-1 [all visible]: a sample that is chunked (-s) has its chunks spread "
+                        "over them (chunk i on GPU i mod N, tables summed by peer copies); small samples go one per GPU")
+    p.add_argument("-gpu", type=int, default=None, help="use exactly this one HIP device (overrides -gpus)")
     p.add_argument("-streams", type=int, default=None,
                    help="engine contexts counting chunks concurrently [2 for one-word keys, else 1]")
     p.add_argument("-canonical", action="store_true",
@@ -96,7 +99,21 @@ def main(argv=None) -> int:
         else:
             parser.error(f"Output folder exists, please specify another folder or use the flag '-replace' to override the files. '{out}'")
     out.mkdir(0o777, True, True)
-    print(f"\nStarting mercat2_amd v{__version__} with k-mer {args.k} on GPU {args.gpu}\n")
+    from . import native
+    visible = native.device_count()
+    if visible < 1:
+        raise SystemExit("mercat2_amd: no HIP device is visible (this engine has no CPU fallback)")
+    if args.gpu is not None:
+        if not 0 <= args.gpu < visible:
+            parser.error(f"-gpu {args.gpu}: {visible} device(s) visible")
+        devices = [args.gpu]
+    else:
+        want = visible if args.gpus is None else args.gpus
+        if not 1 <= want <= visible:
+            parser.error(f"-gpus {want}: {visible} device(s) visible")
+        devices = list(range(want))
+    print(f"\nStarting mercat2_amd v{__version__} with k-mer {args.k} on GPU{'s' if len(devices) > 1 else ''} "
+          f"{','.join(str(d) for d in devices)}\n")
     files = [Path(f) for f in args.i]
     if args.f:
         folder = Path(os.path.abspath(os.path.expanduser(args.f)))
@@ -118,32 +135,42 @@ def main(argv=None) -> int:
         # lines the reference prints per sample are kept and shown in sample order.
         tables = {}  # sample -> its table, kept on the GPU for the combined table
 
-        workers = max(1, min(int(args.n), 8, len(samples[kind])))
+        workers = max(1, min(int(args.n), max(8, 2 * len(devices)), len(samples[kind])))
         threads = max(2, 16 // workers)  # reader/decoder threads per sample: about 16 in all
 
         clean = kind == "nucleotide" and not args.skipclean
 
-        def one(item):
-            base, f = item
+        def one(numbered):
+            idx, (base, f) = numbered
             lines = []
+            # Several GPUs: a sample that is chunked spreads its chunks over all of them (run_sample /
+            # run_text deal chunk i to GPU i mod N); a sample that is one chunk stays on ONE GPU, the samples taking
+            # the GPUs in turn (no exchange at all) -- the reference's one Ray task per sample (bin/mercat2.py:336-339)
+            home = devices[idx % len(devices)]
+            t = {}
+            t0 = timeit.default_timer()
             if clean:
                 # removeN, then count the cleaned text straight from memory; the size of <base>_clean.fna.gz on
                 # disk decides about chunking, as it does in the reference (bin/mercat2.py:101, 243)
-                clean_file, _gc, cleaned = removeN_text(f, out / "clean", args.toupper)
+                clean_file, _gc, cleaned = removeN_text(f, out / "clean", args.toupper, timings=t)
                 chunked = args.s > 0 and os.stat(clean_file).st_size >= args.s * 1024 * 1024
                 run_text(base, cleaned, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, chunked,
-                         device=args.gpu, streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables)
+                         device=home, devices=devices if chunked else None, streams=args.streams, canonical=args.canonical,
+                         report=lines.append, keep=tables, timings=t)
             else:
-                run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=args.gpu,
-                           streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables,
-                           threads=threads if workers > 1 else 0)
+                run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=home,
+                           devices=[home] + [d for d in devices if d != home], streams=args.streams, canonical=args.canonical,
+                           report=lines.append, keep=tables, threads=threads if workers > 1 else 0, timings=t)
+            if args.debug:
+                t["total_s"] = timeit.default_timer() - t0
+                lines.append(f"[debug] {base}: " + " ".join(f"{k_}={v:.3f}" if isinstance(v, float) else f"{k_}={v}" for k_, v in sorted(t.items())))
             return lines
         if workers == 1:
-            results = map(one, samples[kind].items())
+            results = map(one, enumerate(samples[kind].items()))
         else:
             from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(workers)
-            results = pool.map(one, samples[kind].items())
+            results = pool.map(one, enumerate(samples[kind].items()))
         for lines in results:
             for line in lines:
                 print(line)

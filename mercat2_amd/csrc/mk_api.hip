@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 
 typedef unsigned long long u64;
 
@@ -100,7 +101,15 @@ static void prof_collect(mk_ctx* c) {
 }
 
 // ----------------------------------------------------------------------------- lifetime
-extern "C" const char* mk_version(void) { return "mercat_hip 0.1 (gfx950)"; }
+// "mercat_hip <abi>.<minor> (gfx950)": the ABI number changes whenever a struct or a signature of include/mercat_hip.h does
+// (native.py checks it against its own MK_ABI before it trusts the struct layouts)
+extern "C" const char* mk_version(void) { return "mercat_hip 3.0 (gfx950)"; }
+
+extern "C" int mk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n < 0 ? 0 : n;
+}
 
 extern "C" const char* mk_last_error(const mk_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 
@@ -132,6 +141,9 @@ static int settle(mk_ctx* c) {
   fold_pending(c);
   return MK_OK;
 }
+
+int mk_settle(mk_ctx* c) { return settle(c); }
+int mk_pull_info(mk_ctx* c) { return pull_info(c); }
 
 extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   if (!out) { g_err = "mk_create: out is NULL"; return MK_ERR_ARG; }
@@ -199,7 +211,8 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
-                     &c->run_ref, &c->arena, &c->run128, &c->ex128, &c->ex128_out, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2};
+                     &c->run_ref, &c->arena, &c->run128, &c->ex128, &c->ex128_out, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2,
+                     &c->xfer_out, &c->xfer_in, &c->xfer_meta};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->ingest_ring) (void)hipHostFree(c->ingest_ring);
@@ -228,6 +241,7 @@ extern "C" int mk_reset(mk_ctx* c) {
   c->run_side = 0;
   c->in_chunk = false;
   c->raw_len = 0;
+  c->part_reuse_ok = false;  // (a new sample sizes its own bucket regions: nothing is inherited across samples)
   MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
 }
@@ -347,6 +361,12 @@ static int grow_run_ref(mk_ctx* c, size_t need_rows) {
   c->run_ref = nb;
   c->run_ref_slots = slots;
   return MK_OK;
+}
+
+int mk_grow_run(mk_ctx* c, size_t more_rows) {
+  if (c->mode == MK_MODE_HASH64) return grow_run64(c, c->run_rows + more_rows);
+  if (c->mode == MK_MODE_HASH128) return grow_run128(c, c->run128_rows + more_rows);
+  return MK_OK;  // dense bins are allocated once; by-reference rows have their own table
 }
 
 // --------------------------------------------------------------------------- the pipeline
@@ -840,6 +860,7 @@ static void merged_rows(const mk_ctx* c, const ExportView& v, F&& f) {
   }
 }
 
+static int write_view_tsv(mk_ctx* c, const ExportView& v, const char* path, const char* basename, size_t* rows_out);
 static int build_view(mk_ctx* c, ExportView& v) {
   MK_HIP(hipSetDevice(c->device));
   { int rc_ = settle(c); if (rc_) return rc_; }
@@ -887,6 +908,10 @@ extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, s
   ExportView v;
   int rc = build_view(c, v);
   if (rc) return rc;
+  return write_view_tsv(c, v, path, basename, rows_out);
+}
+
+static int write_view_tsv(mk_ctx* c, const ExportView& v, const char* path, const char* basename, size_t* rows_out) {
   const size_t rows = v.packed_rows() + v.rorder.size();
   if (rows_out) *rows_out = rows;
   if (!rows) return MK_OK;  // bin/mercat2.py:135-137: no file when nothing survives
@@ -914,6 +939,111 @@ extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, s
   const bool bad = ferror(f) != 0;
   if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_tsv: write failed: ") + path; return MK_ERR_IO; }
   return MK_OK;
+}
+
+// ----------------------------------------------------- one table spread over several contexts by key range
+// After mk_merge_devices(MK_MERGE_RANGES) context i holds the rows of key range i.  Every context sorts its own
+// rows on its own GPU (one host thread each), the host concatenates the packed rows in context order and merges
+// the few rows kept as text into them.
+static int build_view_multi(mk_ctx* const* ctxs, int n, ExportView& all) {
+  if (!ctxs || n < 1 || !ctxs[0]) return MK_ERR_ARG;
+  mk_ctx* c0 = ctxs[0];
+  for (int j = 0; j < n; ++j) {
+    if (!ctxs[j]) { c0->err = "multi export: a context is NULL"; return MK_ERR_ARG; }
+    if (ctxs[j]->k != c0->k || ctxs[j]->alphabet != c0->alphabet || ctxs[j]->mode != c0->mode) {
+      c0->err = "multi export: contexts differ in alphabet or k";
+      return MK_ERR_ARG;
+    }
+    if (ctxs[j]->in_chunk) { c0->err = "multi export: a chunk is open"; return MK_ERR_STATE; }
+  }
+  std::vector<ExportView> views((size_t)n);
+  std::vector<int> rcs((size_t)n, MK_OK);
+  {
+    std::vector<std::thread> th;
+    for (int j = 1; j < n; ++j) th.emplace_back([&, j] { rcs[j] = build_view(ctxs[j], views[j]); });
+    rcs[0] = build_view(ctxs[0], views[0]);
+    for (auto& t : th) t.join();
+  }
+  for (int j = 0; j < n; ++j)
+    if (rcs[j]) { if (j) c0->err = ctxs[j]->err; return rcs[j]; }
+  all.words = views[0].words;
+  const size_t w = (size_t)all.words, k = (size_t)c0->k;
+  size_t np = 0, nr = 0;
+  for (auto& v : views) { np += v.packed_rows(); nr += v.rorder.size(); }
+  all.pkeys.reserve(np * w);
+  all.pcnts.reserve(np);
+  for (int j = 0; j < n; ++j) {
+    const ExportView& v = views[j];
+    if (!v.packed_rows()) continue;
+    if (!all.pcnts.empty()) {  // ranges ascending and disjoint: last key so far < first key of this context
+      const u64* a = all.pkeys.data() + all.pkeys.size() - w;
+      const u64* b = v.pkeys.data();
+      const bool less = w == 1 ? a[0] < b[0] : (a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]));
+      if (!less) {
+        c0->err = "multi export: context " + std::to_string(j) + " does not continue the key ranges of the contexts before it "
+                  "(call mk_merge_devices with MK_MERGE_RANGES first)";
+        return MK_ERR_STATE;
+      }
+    }
+    all.pkeys.insert(all.pkeys.end(), v.pkeys.begin(), v.pkeys.end());
+    all.pcnts.insert(all.pcnts.end(), v.pcnts.begin(), v.pcnts.end());
+  }
+  if (nr) {  // rows kept as text (after a merge they all sit in ctxs[0]; accept them anywhere): one sorted list
+    all.rstr.reserve(nr * k);
+    for (auto& v : views)
+      for (size_t i = 0; i < v.rorder.size(); ++i) {
+        all.rstr.insert(all.rstr.end(), v.rstr.begin() + v.rorder[i] * k, v.rstr.begin() + (v.rorder[i] + 1) * k);
+        all.rcnt.push_back(v.rcnt[v.rorder[i]]);
+      }
+    all.rorder.resize(nr);
+    for (size_t i = 0; i < nr; ++i) all.rorder[i] = i;
+    std::sort(all.rorder.begin(), all.rorder.end(), [&](u64 x, u64 y) { return memcmp(all.rstr.data() + x * k, all.rstr.data() + y * k, k) < 0; });
+    for (size_t i = 1; i < nr; ++i)
+      if (memcmp(all.rstr.data() + all.rorder[i - 1] * k, all.rstr.data() + all.rorder[i] * k, k) == 0) {
+        c0->err = "multi export: the same text row in two contexts (merge the contexts first)";
+        return MK_ERR_STATE;
+      }
+  }
+  return MK_OK;
+}
+
+extern "C" int mk_export_size_multi(mk_ctx* const* ctxs, int n, size_t* rows) {
+  if (!ctxs || n < 1 || !rows) return MK_ERR_ARG;
+  size_t total = 0;
+  for (int j = 0; j < n; ++j) {
+    size_t r = 0;
+    int rc = mk_export_size(ctxs[j], &r);
+    if (rc) { if (j && ctxs[0] && ctxs[j]) ctxs[0]->err = ctxs[j]->err; return rc; }
+    total += r;
+  }
+  *rows = total;
+  return MK_OK;
+}
+
+extern "C" int mk_export_multi(mk_ctx* const* ctxs, int n, uint8_t* kmers, uint64_t* counts, size_t rows_cap) {
+  ExportView v;
+  int rc = build_view_multi(ctxs, n, v);
+  if (rc) return rc;
+  mk_ctx* c = ctxs[0];
+  const size_t rows = v.packed_rows() + v.rorder.size();
+  if (rows > rows_cap) { c->err = "mk_export_multi: rows_cap too small"; return MK_ERR_RANGE; }
+  if (rows && (!kmers || !counts)) { c->err = "mk_export_multi: NULL output"; return MK_ERR_ARG; }
+  const size_t k = (size_t)c->k;
+  size_t at = 0;
+  merged_rows(c, v, [&](const uint8_t* s, u64 cnt) {
+    memcpy(kmers + at * k, s, k);
+    counts[at] = cnt;
+    ++at;
+  });
+  return MK_OK;
+}
+
+extern "C" int mk_write_tsv_multi(mk_ctx* const* ctxs, int n, const char* path, const char* basename, size_t* rows_out) {
+  if (!path || !basename) return MK_ERR_ARG;
+  ExportView v;
+  int rc = build_view_multi(ctxs, n, v);
+  if (rc) return rc;
+  return write_view_tsv(ctxs[0], v, path, basename, rows_out);
 }
 
 // ------------------------------------------------------------- combined table of several samples
@@ -1167,7 +1297,8 @@ extern "C" int mk_trim(mk_ctx* c) {
   MK_HIP(hipSetDevice(c->device));
   MK_HIP(hipStreamSynchronize(c->stream));
   MkDevBuf* scratch[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->ctab, &c->rtab_chunk, &c->part,
-                         &c->surv_keys, &c->surv_cnts, &c->surv_keys2, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->ex128, &c->ex128_out};
+                         &c->surv_keys, &c->surv_cnts, &c->surv_keys2, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->ex128, &c->ex128_out,
+                         &c->xfer_out, &c->xfer_in};
   for (auto* b : scratch)
     if (!(b == &c->ctab && c->mode == MK_MODE_DENSE)) buf_free(*b);  // the dense bins are allocated once, at mk_create
   if (c->mode != MK_MODE_DENSE) c->ctab_slots = 0;
@@ -1316,11 +1447,14 @@ extern "C" int mk_merge_from(mk_ctx* dst, mk_ctx* src) {
   if (dst->in_chunk || src->in_chunk) { c->err = "mk_merge_from: a chunk is open"; return MK_ERR_STATE; }
   MK_HIP(hipSetDevice(dst->device));
   int rc;
+  // both streams idle before one context's kernels touch the other's buffers (whatever the mode: the export of src
+  // writes into dst's survivor buffers, which dst's own merge kernels may still be reading)
+  if ((rc = settle(src)) != MK_OK) { dst->err = src->err; return rc; }
+  if ((rc = settle(dst)) != MK_OK) return rc;
+  MK_HIP(hipStreamSynchronize(src->stream));
+  MK_HIP(hipStreamSynchronize(dst->stream));
   if (src->mode == MK_MODE_HASH64) {
     // table to table, on the device: no compaction, no sort (the rows' order does not matter for a sum)
-    if ((rc = settle(src)) != MK_OK) { dst->err = src->err; return rc; }
-    if ((rc = settle(dst)) != MK_OK) return rc;
-    MK_HIP(hipStreamSynchronize(src->stream));
     if (src->run_rows) {
       if ((rc = grow_run64(dst, dst->run_rows + src->run_rows)) != MK_OK) return rc;
       MK_HIP(hipMemsetAsync(dst->info.p, 0, sizeof(MkChunkInfo), dst->stream));

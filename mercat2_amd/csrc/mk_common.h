@@ -166,6 +166,10 @@ struct mk_ctx {
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
   MkDevBuf ex128, ex128_out;  // two-word rows: compacted {hi, lo, count} + sort scratch; sorted rows for the host
 
+  // multi-GPU merge staging (mk_multi.hip): rows grouped by owner going out, rows received from the peers,
+  // owner bounds + histogram + cursors
+  MkDevBuf xfer_out, xfer_in, xfer_meta;
+
   // pinned block ring of mk_count_file (mk_ingest.hip), kept between files
   void* ingest_ring = nullptr;
   size_t ingest_ring_bytes = 0;
@@ -247,6 +251,13 @@ int mk_launch_compact(mk_ctx* c, const MkSlot* t, size_t slots, uint64_t* d_keys
                       uint64_t* d_cursor);
 int mk_sort_pairs(mk_ctx* c, const uint64_t* keys_in, const uint64_t* vals_in, uint64_t* keys_out, uint64_t* vals_out,
                   size_t n, int key_bits);
+
+// mk_api.hip, for mk_multi.hip
+int mk_settle(mk_ctx* c);                      // fold row totals that were read back without waiting
+int mk_pull_info(mk_ctx* c);                   // MkChunkInfo -> h_info, stream idle afterwards
+int mk_grow_run(mk_ctx* c, size_t more_rows);  // room in the packed running table for more_rows further keys
+// mk_table.hip: interleaved rows {key word(s), count} -> running table (dense: {bin, count})
+int mk_launch_import_rows(mk_ctx* c, const uint64_t* d_rows, size_t rows);
 
 void mk_prof_begin(mk_ctx* c, int id);
 void mk_prof_end(mk_ctx* c);

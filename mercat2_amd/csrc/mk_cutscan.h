@@ -26,7 +26,12 @@ struct MkCutSink {
 
 class MkCutScanner {
  public:
-  MkCutScanner(uint64_t chunksize, MkCutSink* sink) : chunksize_(chunksize), sink_(sink) {}
+  // record_starts_only: a line opens the next chunk only if it STARTS a record -- its first non-blank byte is '>'
+  // (what find_kmers takes for a header after line.strip(), lib/mercat2_kmers.py:51-52) -- instead of merely
+  // containing '>' (the Chunker's rule).  For pieces of ONE filter unit counted on several GPUs: no window may span
+  // a cut, and a sequence line such as "AC>GT" is not a record boundary.
+  MkCutScanner(uint64_t chunksize, MkCutSink* sink, bool record_starts_only = false)
+      : chunksize_(chunksize), sink_(sink), strict_(record_starts_only) {}
 
   // Next block of the text. has_cr: the block holds at least one '\r' (pass true when unknown).
   int block(const uint8_t* p, size_t n, bool has_cr) {
@@ -61,6 +66,7 @@ class MkCutScanner {
         mid_line_ = true;
         armed_ = written_ >= chunksize_;
         has_delim_ = false;
+        decided_ = false;
         line_len_ = 0;
         line_abs_ = base_ + pos;
         lp_ = pos;
@@ -75,7 +81,14 @@ class MkCutScanner {
         const uint8_t* cr = (const uint8_t*)memchr(q, '\r', len);
         if (cr) { len = (size_t)(cr - q); term = true; }
       }
-      if (armed_ && !has_delim_ && memchr(q, '>', len)) has_delim_ = true;
+      if (armed_ && !strict_ && !has_delim_ && memchr(q, '>', len)) has_delim_ = true;
+      if (armed_ && strict_ && !decided_) {
+        for (size_t t = 0; t < len; ++t) {
+          const uint8_t ch = q[t];
+          const bool blank = ch == ' ' || (ch >= 0x09 && ch <= 0x0D) || (ch >= 0x1C && ch <= 0x1F);  // str.strip(), ASCII
+          if (!blank) { has_delim_ = ch == '>'; decided_ = true; break; }
+        }
+      }
       line_len_ += len;
       if (!term) {  // the line goes on in the next block
         if (armed_) {
@@ -155,6 +168,8 @@ class MkCutScanner {
   bool mid_line_ = false;   // a line is in progress
   bool armed_ = false;      // ... and it started at or past the threshold (it cuts if it holds '>')
   bool has_delim_ = false;
+  bool strict_ = false;     // cut at record starts only (see the constructor)
+  bool decided_ = false;    // strict: the first non-blank byte of the line in progress has been seen
   uint64_t line_len_ = 0;   // content bytes of the line in progress seen so far
   uint64_t line_abs_ = 0;   // absolute offset of its first byte
   size_t lp_ = 0;           // where its bytes start in the current block

@@ -75,12 +75,24 @@ struct RecordingSink : MkCutSink {
 };
 }  // namespace
 
+static int stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts, size_t cap,
+                       size_t* ncuts, bool record_starts_only);
 extern "C" int mk_stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts,
                               size_t cap, size_t* ncuts) {
+  return stream_cuts(text, n, chunksize, block, cuts, cap, ncuts, false);
+}
+// The cuts mk_count_file makes when it splits ONE filter unit (a file below the chunk size) over several GPUs:
+// pieces of at least `piece` bytes that end where a record starts (first non-blank byte of the line is '>').
+extern "C" int mk_record_cuts(const uint8_t* text, size_t n, uint64_t piece, size_t block, uint64_t* cuts, size_t cap,
+                              size_t* ncuts) {
+  return stream_cuts(text, n, piece, block, cuts, cap, ncuts, true);
+}
+static int stream_cuts(const uint8_t* text, size_t n, uint64_t chunksize, size_t block, uint64_t* cuts, size_t cap,
+                       size_t* ncuts, bool record_starts_only) {
   if (!ncuts || (n && !text) || block == 0) return MK_ERR_ARG;
   RecordingSink sink;
   sink.text = text;
-  MkCutScanner scan(chunksize, &sink);
+  MkCutScanner scan(chunksize, &sink, record_starts_only);
   for (size_t off = 0; off < n; off += block) {
     const size_t m = n - off < block ? n - off : block;
     scan.block(text + off, m, memchr(text + off, '\r', m) != nullptr);
@@ -392,3 +404,23 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
 }
 
 extern "C" void mk_free(void* p) { free(p); }
+
+// ---- planning helpers of the multi-GPU path (no GPU needed) -------------------------------------------------
+// First key of owner 1..n-1 when [0, 2^key_bits) is cut into n equal ranges (the same cut as
+// mercat2_amd.dist.range_bounds): owner of a key = number of bounds <= key.
+extern "C" int mk_owner_bounds(int key_bits, int n, uint64_t* bounds) {
+  if (key_bits < 1 || key_bits > 64 || n < 1 || (n > 1 && !bounds)) return MK_ERR_ARG;
+  for (int i = 1; i < n; ++i) {
+    const unsigned __int128 span = (unsigned __int128)1 << key_bits;
+    bounds[i - 1] = (uint64_t)((span * (unsigned)i + (unsigned)n - 1) / (unsigned)n);
+  }
+  return MK_OK;
+}
+
+// Context creation order for mk_count_file over several devices: chunk i -> ctxs[i mod nctx] must mean
+// device devices[i mod ndev], and the chunks of one device must take turns on its streams.
+extern "C" int mk_plan_contexts(const int* devices, int ndev, int streams, int* ctx_device) {
+  if (!devices || !ctx_device || ndev < 1 || streams < 1) return MK_ERR_ARG;
+  for (int j = 0; j < ndev * streams; ++j) ctx_device[j] = devices[j % ndev];
+  return MK_OK;
+}

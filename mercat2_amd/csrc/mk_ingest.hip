@@ -13,6 +13,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -377,9 +378,8 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   for (int j = 0; j < nctx; ++j) {
     if (!ctxs[j]) { c0->err = "mk_count_file: a context is NULL"; return MK_ERR_ARG; }
     if (ctxs[j]->in_chunk) { c0->err = "mk_count_file: a chunk is open"; return MK_ERR_STATE; }
-    if (ctxs[j]->device != c0->device || ctxs[j]->alphabet != c0->alphabet || ctxs[j]->k != c0->k ||
-        ctxs[j]->canonical != c0->canonical) {
-      c0->err = "mk_count_file: contexts differ in device, alphabet, k or canonical mode";
+    if (ctxs[j]->alphabet != c0->alphabet || ctxs[j]->k != c0->k || ctxs[j]->canonical != c0->canonical) {
+      c0->err = "mk_count_file: contexts differ in alphabet, k or canonical mode";
       return MK_ERR_ARG;
     }
     for (int i = 0; i < j; ++i)
@@ -396,7 +396,29 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   const bool gz = spath.size() >= 3 && spath.compare(spath.size() - 3, 3, ".gz") == 0;
   // chunk iff the ON-DISK size reaches the chunk size (bin/mercat2.py:101)
   const bool chunked = chunk_bytes > 0 && disk >= chunk_bytes;
-  const int lanes_n = chunked ? nctx : 1;
+  // the GPUs the contexts are on, in order of first appearance
+  // (MK_DEVICE_PER_CONTEXT=1, for tests on a one-GPU box: every context counts as a GPU of its own, so the several-GPU
+  // code path -- per-GPU leaders, mk_merge_devices, the split of a single filter unit -- runs with device list [0, 0, ..])
+  const bool each_own = getenv("MK_DEVICE_PER_CONTEXT") != nullptr;
+  auto group_of = [&](int j) { return each_own ? -1 - j : ctxs[j]->device; };
+  std::vector<int> devs;
+  for (int j = 0; j < nctx; ++j)
+    if (std::find(devs.begin(), devs.end(), group_of(j)) == devs.end()) devs.push_back(group_of(j));
+  // One filter unit (not chunked) on several GPUs: counted in pieces cut at record starts, unfiltered, filtered after
+  // the sum -- when it is large enough to be worth the larger merge.  MK_SPLIT_MIN = bytes of text.
+  uint64_t text_guess = disk;
+  if (gz && disk >= 18) {
+    uint8_t tail[4];
+    text_guess = disk * 4;
+    if (pread(fd, tail, 4, (off_t)disk - 4) == 4) {  // ISIZE of the last member: exact for a one-member file below 4 GiB
+      const uint64_t isize = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24);
+      text_guess = std::max<uint64_t>(isize, disk);
+    }
+  }
+  const uint64_t split_min = getenv("MK_SPLIT_MIN") ? (uint64_t)atoll(getenv("MK_SPLIT_MIN")) : ((uint64_t)64 << 20);
+  const bool split = !chunked && devs.size() > 1 && text_guess >= split_min && c0->mode != MK_MODE_BYREF;
+  const uint64_t piece_bytes = split ? std::max<uint64_t>((text_guess + (uint64_t)nctx - 1) / (uint64_t)nctx, std::min<uint64_t>(split_min, (uint64_t)8 << 20)) : 0;
+  const int lanes_n = (chunked || split) ? nctx : 1;
 
   const bool auto_threads = threads <= 0;
   if (auto_threads) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
@@ -441,7 +463,8 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
       if (c0->ingest_ring) (void)hipHostFree(c0->ingest_ring);
       c0->ingest_ring = nullptr;
       c0->ingest_ring_bytes = 0;
-      const hipError_t he = hipHostMalloc(&c0->ingest_ring, bytes, hipHostMallocDefault);
+      // (portable: every GPU the contexts are on copies out of it)
+      const hipError_t he = hipHostMalloc(&c0->ingest_ring, bytes, hipHostMallocPortable);
       if (he != hipSuccess) {
         c0->err = "hipHostMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(he);
         if (gz_map) (void)munmap(gz_map, (size_t)disk);
@@ -460,6 +483,8 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   size_t reserve = 0;
   if (chunked) {
     reserve = (size_t)chunk_bytes + ((size_t)8 << 20);
+  } else if (split) {
+    reserve = (size_t)piece_bytes + ((size_t)8 << 20);
   } else if (!gz) {
     reserve = (size_t)disk + 64;
   } else if (disk >= 18) {
@@ -478,8 +503,9 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   std::vector<hipEvent_t> events((size_t)R.slots * lanes_n, nullptr);
   std::vector<char> ev_set((size_t)R.slots * lanes_n, 0);
   int rc = MK_OK;
-  for (auto& e : events)
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) rc = MK_ERR_HIP;
+  for (size_t e = 0; e < events.size(); ++e)  // (an event belongs to the device that is current when it is made)
+    if (hipSetDevice(lanes[e % (size_t)lanes_n].c->device) != hipSuccess ||
+        hipEventCreateWithFlags(&events[e], hipEventDisableTiming) != hipSuccess) rc = MK_ERR_HIP;
 
   int members = 0;
   std::atomic<int> bgzf_members{0};
@@ -505,9 +531,9 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   Dispatcher D;
   D.lanes = &lanes;
   D.ring = &R;
-  D.min_count = min_count;
+  D.min_count = split ? 0 : min_count;  // (pieces of one filter unit: the filter comes after the sum)
   D.reserve = reserve;
-  MkCutScanner scan(chunked ? chunk_bytes : UINT64_MAX, &D);
+  MkCutScanner scan(chunked ? chunk_bytes : (split ? piece_bytes : UINT64_MAX), &D, /*record_starts_only=*/split);
   uint64_t text_bytes = 0;
   double s_wait_io = 0;
   const uint64_t lag = (uint64_t)R.slots / 2;
@@ -532,7 +558,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     text_bytes += n;
     for (int j : D.touched) {
       const size_t e = (size_t)s * lanes_n + j;
-      if (hipEventRecord(events[e], lanes[j].c->stream) != hipSuccess) { rc = MK_ERR_HIP; break; }
+      if (hipSetDevice(lanes[j].c->device) != hipSuccess || hipEventRecord(events[e], lanes[j].c->stream) != hipSuccess) { rc = MK_ERR_HIP; break; }
       ev_set[e] = 1;
     }
     if (i >= lag) retire(i - lag);
@@ -570,21 +596,35 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     else if (D.rc_lane > 0) c0->err = ctxs[D.rc_lane]->err;
     return rc;
   }
-  // the sample's table ends up in ctxs[0]
-  for (int j = 1; j < lanes_n; ++j) {
-    if ((rc = mk_merge_from(c0, ctxs[j])) != MK_OK) return rc;
+  // the sample's table ends up in ctxs[0]: the contexts of one GPU are summed on that GPU into the first of them,
+  // then the GPUs' tables are summed into ctxs[0] (peer copies, mk_multi.hip)
+  const auto t_merge = Clock::now();
+  std::vector<mk_ctx*> leaders;
+  std::vector<int> leader_group;
+  for (int j = 0; j < lanes_n; ++j) {
+    mk_ctx* lead = nullptr;
+    for (size_t l = 0; l < leaders.size(); ++l)
+      if (leader_group[l] == group_of(j)) lead = leaders[l];
+    if (!lead) { leaders.push_back(ctxs[j]); leader_group.push_back(group_of(j)); continue; }
+    if ((rc = mk_merge_from(lead, ctxs[j])) != MK_OK) { if (lead != c0) c0->err = lead->err; return rc; }
     if ((rc = mk_reset(ctxs[j])) != MK_OK) { c0->err = ctxs[j]->err; return rc; }
   }
+  if (leaders.size() > 1 && (rc = mk_merge_devices(leaders.data(), (int)leaders.size(), MK_MERGE_GATHER, nullptr)) != MK_OK) return rc;
+  if (split && (rc = mk_filter_min(c0, min_count)) != MK_OK) return rc;
+  const double s_merge = seconds_since(t_merge);
   if (st) {
     memset(st, 0, sizeof *st);
     st->disk_bytes = disk;
     st->text_bytes = text_bytes;
-    st->chunks = D.chunks;
+    st->chunks = split ? 1 : D.chunks;
     st->gz = gz ? 1 : 0;
     st->chunked = chunked ? 1 : 0;
     st->members = members + bgzf_members.load();
     st->threads = threads;
     st->contexts = lanes_n;
+    st->devices = (int)leaders.size();
+    st->split_pieces = split ? (int)D.chunks : 0;
+    st->s_merge = s_merge;
     st->s_wait_io = s_wait_io;
     st->s_wait_gpu = D.s_wait_gpu;
     st->s_total = seconds_since(t_begin);

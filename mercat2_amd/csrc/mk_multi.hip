@@ -1,0 +1,552 @@
+// mk_multi.hip -- one process, several GPUs: the merge of the per-GPU count tables.
+//
+// Replaces the reference's cross-worker merge -- ray.get of every chunk's dict and the dict sum in run_mercat2
+// (bin/mercat2.py:121-127), the workers being the Ray tasks of bin/mercat2.py:119-120,336-339 -- for the GPUs of one
+// node driven by ONE process.  Chunks are the shard unit (mk_count_file deals chunk i to ctxs[i mod nctx], every chunk
+// filtered on its own GPU: the per-chunk min_count rule needs no exchange); the one exchange step is this merge:
+//   1. every context groups the rows of its running table by OWNER (owner = key range of the first key word):
+//      one histogram pass and one scatter pass over the table, no sort;
+//   2. the segments are copied straight to their owners' GPUs with peer copies -- each pair of GPUs has its own xGMI
+//      link, so in round s source i sends to owner (i + s) mod n and all links carry rows at once;
+//   3. every owner insert-adds its own segment and what it received into its (emptied) running table.
+// Rows kept as text (characters outside the alphabet, k > 64: rare) go through the host into ctxs[0].
+// The same two device primitives serve one-process-per-GPU callers (mercat2_amd/dist.py over RCCL) through
+// mk_bucket_rows_device / mk_import_rows_device.
+#include "mk_common.h"
+#include "mk_device.h"
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <thread>
+
+#define MK_MAX_OWNERS 64
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+static double secs(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+// ---- the three packed running tables seen as "slot i -> (occupied, key word(s), count)" ------------------------
+struct View64 {
+  const MkSlot* t;
+  static constexpr int W = 1;
+  __device__ __forceinline__ bool get(size_t i, u64& a, u64& b, u64& c) const {
+    const ulonglong2 s = reinterpret_cast<const ulonglong2*>(t)[i];
+    a = s.x; b = 0; c = s.y;
+    return s.x != MK_EMPTY && s.y != 0;
+  }
+};
+struct View128 {
+  const MkSlot128* t;
+  static constexpr int W = 2;
+  __device__ __forceinline__ bool get(size_t i, u64& a, u64& b, u64& c) const {
+    const ulonglong4 s = reinterpret_cast<const ulonglong4*>(t)[i];
+    a = s.x; b = s.y; c = s.z;
+    return s.z != 0;
+  }
+};
+struct ViewDense {
+  const u64* bins;
+  static constexpr int W = 1;
+  __device__ __forceinline__ bool get(size_t i, u64& a, u64& b, u64& c) const {
+    a = (u64)i; b = 0; c = bins[i];
+    return c != 0;
+  }
+};
+
+__device__ __forceinline__ int owner_of(const u64* __restrict__ s_bounds, int n, u64 key) {
+  int o = 0;
+  for (int j = 0; j + 1 < n; ++j) o += key >= s_bounds[j] ? 1 : 0;
+  return o;
+}
+
+// rows per owner
+template <class V>
+__global__ __launch_bounds__(256) void mk_owner_hist_k(V v, size_t slots, const u64* __restrict__ bounds, int n, u64* __restrict__ hist) {
+  __shared__ u64 s_bounds[MK_MAX_OWNERS];
+  __shared__ unsigned s_cnt[MK_MAX_OWNERS];
+  if (threadIdx.x < MK_MAX_OWNERS) {
+    s_cnt[threadIdx.x] = 0;
+    s_bounds[threadIdx.x] = (int)threadIdx.x + 1 < n ? bounds[threadIdx.x] : ~0ull;
+  }
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
+    u64 a, b, c;
+    if (v.get(i, a, b, c)) atomicAdd(&s_cnt[owner_of(s_bounds, n, a)], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n && s_cnt[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)s_cnt[threadIdx.x]);
+}
+
+// rows grouped by owner: every workgroup owns a contiguous slice of the table, counts its rows per owner, reserves
+// its part of every owner's segment with one atomic per owner (cursor[j] starts at the segment's first row), and
+// places its rows (the slice is L2-hot on the second pass).  Rows are W + 1 words: {key word(s), count}.
+template <class V>
+__global__ __launch_bounds__(256) void mk_owner_scatter_k(V v, size_t slots, const u64* __restrict__ bounds, int n,
+                                                           u64* __restrict__ cursor, u64* __restrict__ out, u64 cap_rows) {
+  __shared__ u64 s_bounds[MK_MAX_OWNERS];
+  __shared__ unsigned s_cnt[MK_MAX_OWNERS];
+  __shared__ u64 s_base[MK_MAX_OWNERS];
+  if (threadIdx.x < MK_MAX_OWNERS) {
+    s_cnt[threadIdx.x] = 0;
+    s_bounds[threadIdx.x] = (int)threadIdx.x + 1 < n ? bounds[threadIdx.x] : ~0ull;
+  }
+  __syncthreads();
+  const size_t per = (slots + gridDim.x - 1) / gridDim.x;
+  const size_t lo = (size_t)blockIdx.x * per, hi = lo + per < slots ? lo + per : slots;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u64 a, b, c;
+    if (v.get(i, a, b, c)) atomicAdd(&s_cnt[owner_of(s_bounds, n, a)], 1u);
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    s_base[threadIdx.x] = s_cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (u64)s_cnt[threadIdx.x]) : 0ull;
+    s_cnt[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  constexpr int RW = V::W + 1;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    u64 a, b, c;
+    if (!v.get(i, a, b, c)) continue;
+    const int o = owner_of(s_bounds, n, a);
+    const u64 pos = s_base[o] + atomicAdd(&s_cnt[o], 1u);
+    if (pos >= cap_rows) continue;  // (cannot happen: the histogram sized the segments; never write past the buffer)
+    if (V::W == 1) {
+      reinterpret_cast<ulonglong2*>(out)[pos] = make_ulonglong2(a, c);
+    } else {
+      out[pos * RW] = a;
+      out[pos * RW + 1] = b;
+      out[pos * RW + 2] = c;
+    }
+  }
+}
+
+// first key words of the rows in every stride-th slot (the table is hashed: a uniform sample of its rows)
+template <class V>
+__global__ void mk_sample_keys_k(V v, size_t slots, size_t stride, u64* __restrict__ out, u64 cap, u64* __restrict__ cursor) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j * stride < slots; j += (size_t)gridDim.x * blockDim.x) {
+    u64 a, b, c;
+    if (v.get(j * stride, a, b, c)) {
+      const u64 pos = atomicAdd(cursor, 1ull);
+      if (pos < cap) out[pos] = a;
+    }
+  }
+}
+
+static unsigned grid_for(size_t items, unsigned per_block, unsigned cap) {
+  size_t g = (items + per_block - 1) / per_block;
+  if (g > cap) g = cap;
+  if (g == 0) g = 1;
+  return (unsigned)g;
+}
+
+struct TableRef {
+  int kind = 0;  // 0 none, 1 one-word, 2 two-word, 3 dense
+  const void* p = nullptr;
+  size_t slots = 0;
+  size_t rows = 0;  // rows the host knows of (dense: unknown, bins)
+};
+static TableRef table_of(const mk_ctx* c) {
+  TableRef t;
+  if (c->mode == MK_MODE_HASH64 && c->run_slots) { t.kind = 1; t.p = c->run.p; t.slots = c->run_slots; t.rows = c->run_rows; }
+  else if (c->mode == MK_MODE_HASH128 && c->run128_slots) { t.kind = 2; t.p = c->run128.p; t.slots = c->run128_slots; t.rows = c->run128_rows; }
+  else if (c->mode == MK_MODE_DENSE) { t.kind = 3; t.p = c->run.p; t.slots = c->run_slots; t.rows = c->run_slots; }
+  return t;
+}
+
+// meta buffer: bounds[64] | hist[64] | cursor[64]
+static int reserve_meta(mk_ctx* c) { return mk_buf_reserve(c, c->xfer_meta, 3 * MK_MAX_OWNERS * sizeof(u64)); }
+
+// counts[j] = rows of owner j; with d_rows the rows themselves, owner after owner.  The one key that lives beside
+// the one-word table (the all-T 32-mer) goes to owner side_owner as an ordinary row (the import sets it aside again).
+static int bucket_rows(mk_ctx* c, const u64* bounds, int n, u64* d_rows, size_t cap_rows, u64* counts, int side_owner) {
+  int rc;
+  for (int j = 0; j < n; ++j) counts[j] = 0;
+  MK_HIP(hipSetDevice(c->device));
+  if ((rc = mk_settle(c)) != MK_OK) return rc;
+  const TableRef t = table_of(c);
+  const bool side = c->mode == MK_MODE_HASH64 && c->run_side != 0;
+  if (t.kind && t.rows) {
+    if ((rc = reserve_meta(c)) != MK_OK) return rc;
+    u64* d_bounds = (u64*)c->xfer_meta.p;
+    u64* d_hist = d_bounds + MK_MAX_OWNERS;
+    u64 hb[MK_MAX_OWNERS];
+    for (int j = 0; j < MK_MAX_OWNERS; ++j) hb[j] = j + 1 < n ? bounds[j] : ~0ull;
+    MK_HIP(hipMemcpyAsync(d_bounds, hb, sizeof hb, hipMemcpyHostToDevice, c->stream));
+    MK_HIP(hipMemsetAsync(d_hist, 0, MK_MAX_OWNERS * sizeof(u64), c->stream));
+    const unsigned grid = grid_for(t.slots, 256 * 16, 2048);
+    if (t.kind == 1) hipLaunchKernelGGL(mk_owner_hist_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
+    else if (t.kind == 2) hipLaunchKernelGGL(mk_owner_hist_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
+    else hipLaunchKernelGGL(mk_owner_hist_k<ViewDense>, dim3(grid), dim3(256), 0, c->stream, ViewDense{(const u64*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
+    MK_HIP(hipGetLastError());
+    u64 hh[MK_MAX_OWNERS];
+    MK_HIP(hipMemcpyAsync(hh, d_hist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < n; ++j) counts[j] = hh[j];
+  }
+  if (side) counts[side_owner] += 1;
+  if (!d_rows) return MK_OK;
+  u64 total = 0;
+  for (int j = 0; j < n; ++j) total += counts[j];
+  if (total > cap_rows) { c->err = "rows by owner: buffer of " + std::to_string(cap_rows) + " rows is too small for " + std::to_string(total); return MK_ERR_RANGE; }
+  const int rw = mk_words_per_key(c) + 1;
+  if (t.kind && t.rows) {
+    u64* d_bounds = (u64*)c->xfer_meta.p;
+    u64* d_cursor = d_bounds + 2 * MK_MAX_OWNERS;
+    u64 cur[MK_MAX_OWNERS], at = 0;
+    for (int j = 0; j < MK_MAX_OWNERS; ++j) {
+      cur[j] = at;
+      if (j < n) at += counts[j];
+    }
+    MK_HIP(hipMemcpyAsync(d_cursor, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));
+    const unsigned grid = grid_for(t.slots, 256 * 16, 2048);
+    if (t.kind == 1) hipLaunchKernelGGL(mk_owner_scatter_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+    else if (t.kind == 2) hipLaunchKernelGGL(mk_owner_scatter_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+    else hipLaunchKernelGGL(mk_owner_scatter_k<ViewDense>, dim3(grid), dim3(256), 0, c->stream, ViewDense{(const u64*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+    MK_HIP(hipGetLastError());
+  }
+  if (side) {  // the last row of its owner's segment (the kernel filled counts - 1 rows of it)
+    u64 at = 0;
+    for (int j = 0; j <= side_owner; ++j) at += counts[j];
+    const u64 row[2] = {MK_EMPTY, c->run_side};
+    MK_HIP(hipMemcpyAsync(d_rows + (at - 1) * (u64)rw, row, sizeof row, hipMemcpyHostToDevice, c->stream));
+  }
+  MK_HIP(hipStreamSynchronize(c->stream));
+  return MK_OK;
+}
+
+// about `want` first key words of the context's rows (for MK_MERGE_BALANCED), every stride-th slot
+static int sample_keys(mk_ctx* c, size_t stride, std::vector<u64>& out) {
+  int rc;
+  MK_HIP(hipSetDevice(c->device));
+  if ((rc = mk_settle(c)) != MK_OK) return rc;
+  const TableRef t = table_of(c);
+  if (!(t.kind == 1 || t.kind == 2) || !t.rows) return MK_OK;
+  const size_t cap = 2 * (t.rows / stride) + 1024;
+  if ((rc = mk_buf_reserve(c, c->xfer_in, (cap + 8) * sizeof(u64))) != MK_OK) return rc;
+  u64* d_cursor = (u64*)c->xfer_in.p;
+  u64* d_out = d_cursor + 8;
+  MK_HIP(hipMemsetAsync(d_cursor, 0, 8, c->stream));
+  const unsigned grid = grid_for(t.slots / stride + 1, 256, 1024);
+  if (t.kind == 1) hipLaunchKernelGGL(mk_sample_keys_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, stride, d_out, (u64)cap, d_cursor);
+  else hipLaunchKernelGGL(mk_sample_keys_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, stride, d_out, (u64)cap, d_cursor);
+  MK_HIP(hipGetLastError());
+  u64 got = 0;
+  MK_HIP(hipMemcpyAsync(&got, d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  if (got > cap) got = cap;
+  const size_t at = out.size();
+  out.resize(at + (size_t)got);
+  if (got) {
+    MK_HIP(hipMemcpyAsync(out.data() + at, d_out, (size_t)got * 8, hipMemcpyDeviceToHost, c->stream));
+    MK_HIP(hipStreamSynchronize(c->stream));
+  }
+  return MK_OK;
+}
+
+// direct access between two devices, both ways; 1 = direct (xGMI / PCIe P2P), 0 = hipMemcpyPeer stages the bytes itself
+static int enable_peer_pair(int a, int b) {
+  if (a == b) return 1;
+  int ok = 1;
+  const int pair[2][2] = {{a, b}, {b, a}};
+  for (auto& p : pair) {
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, p[0], p[1]) != hipSuccess || !can) { ok = 0; continue; }
+    if (hipSetDevice(p[0]) != hipSuccess) { ok = 0; continue; }
+    const hipError_t e = hipDeviceEnablePeerAccess(p[1], 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = 0;
+    (void)hipGetLastError();  // (already-enabled is not an error to carry along)
+  }
+  return ok;
+}
+
+template <class F>
+static int on_every(int n, F&& f) {  // f(i) for every context at once (each has host waits of its own); first error wins
+  std::vector<int> rcs((size_t)n, MK_OK);
+  std::vector<std::thread> th;
+  for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rcs[i] = f(i); });
+  rcs[0] = f(0);
+  for (auto& t : th) t.join();
+  for (int i = 0; i < n; ++i)
+    if (rcs[i]) return rcs[i];
+  return MK_OK;
+}
+
+}  // namespace
+
+extern "C" int mk_bucket_rows_device(mk_ctx* c, const uint64_t* bounds, int n, uint64_t* d_rows, size_t cap_rows, uint64_t* counts) {
+  if (!c || !counts || n < 1 || (n > 1 && !bounds)) return MK_ERR_ARG;
+  if (n > MK_MAX_OWNERS) { c->err = "mk_bucket_rows_device: at most 64 owners"; return MK_ERR_ARG; }
+  if (c->in_chunk) { c->err = "mk_bucket_rows_device: a chunk is open"; return MK_ERR_STATE; }
+  for (int j = 1; j + 1 < n; ++j)
+    if (bounds[j] < bounds[j - 1]) { c->err = "mk_bucket_rows_device: bounds must ascend"; return MK_ERR_ARG; }
+  return bucket_rows(c, (const u64*)bounds, n, (u64*)d_rows, cap_rows, (u64*)counts, n - 1);
+}
+
+extern "C" int mk_import_rows_device(mk_ctx* c, const uint64_t* d_rows, size_t rows) {
+  if (!c) return MK_ERR_ARG;
+  if (!rows) return MK_OK;
+  if (!d_rows) return MK_ERR_ARG;
+  if (c->mode == MK_MODE_BYREF) { c->err = "mk_import_rows_device: context has no packed table"; return MK_ERR_STATE; }
+  int rc;
+  if ((rc = mk_settle(c)) != MK_OK) return rc;
+  MK_HIP(hipSetDevice(c->device));
+  MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
+  if ((rc = mk_grow_run(c, rows)) != MK_OK) return rc;
+  if ((rc = mk_launch_import_rows(c, d_rows, rows)) != MK_OK) return rc;
+  if ((rc = mk_pull_info(c)) != MK_OK) return rc;
+  if (c->mode == MK_MODE_HASH128) c->run128_rows += (size_t)c->h_info->new_rows;
+  else if (c->mode == MK_MODE_HASH64) { c->run_rows += (size_t)c->h_info->new_rows; c->run_side += c->h_info->side; }
+  return MK_OK;
+}
+
+extern "C" int mk_sample_keys(mk_ctx* c, size_t stride, uint64_t* out, size_t cap, size_t* n) {
+  if (!c || !n || (cap && !out)) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_sample_keys: a chunk is open"; return MK_ERR_STATE; }
+  std::vector<u64> got;
+  int rc = sample_keys(c, stride ? stride : 1, got);
+  if (rc) return rc;
+  *n = got.size() < cap ? got.size() : cap;
+  if (*n) memcpy(out, got.data(), *n * sizeof(u64));
+  return MK_OK;
+}
+
+// The dense histogram (small k) as one array: out to / in from a caller's DEVICE buffer, so that several GPUs can
+// sum their bins with one reduce ("dense bins: ncclAllReduce / ncclReduce of u64 bins").
+extern "C" int mk_dense_bins_device(mk_ctx* c, uint64_t* d_bins, size_t nbins, int store) {
+  if (!c || !d_bins) return MK_ERR_ARG;
+  if (c->mode != MK_MODE_DENSE) { c->err = "mk_dense_bins_device: the context does not count into dense bins"; return MK_ERR_STATE; }
+  if (c->in_chunk) { c->err = "mk_dense_bins_device: a chunk is open"; return MK_ERR_STATE; }
+  if (nbins != c->run_slots) { c->err = "mk_dense_bins_device: the table has " + std::to_string(c->run_slots) + " bins"; return MK_ERR_RANGE; }
+  int rc;
+  if ((rc = mk_settle(c)) != MK_OK) return rc;
+  MK_HIP(hipSetDevice(c->device));
+  if (store) MK_HIP(hipMemcpyAsync(c->run.p, d_bins, nbins * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  else MK_HIP(hipMemcpyAsync(d_bins, c->run.p, nbins * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  return MK_OK;
+}
+
+extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_stats_t* st) {
+  if (!ctxs || n < 1 || !ctxs[0]) return MK_ERR_ARG;
+  mk_ctx* c0 = ctxs[0];
+  if (n > MK_MAX_OWNERS) { c0->err = "mk_merge_devices: at most 64 contexts"; return MK_ERR_ARG; }
+  for (int i = 0; i < n; ++i) {
+    mk_ctx* c = ctxs[i];
+    if (!c) { c0->err = "mk_merge_devices: a context is NULL"; return MK_ERR_ARG; }
+    if (c->alphabet != c0->alphabet || c->k != c0->k || c->canonical != c0->canonical || c->mode != c0->mode) {
+      c0->err = "mk_merge_devices: contexts differ in alphabet, k or canonical mode";
+      return MK_ERR_ARG;
+    }
+    if (c->in_chunk) { c0->err = "mk_merge_devices: a chunk is open"; return MK_ERR_STATE; }
+    for (int j = 0; j < i; ++j)
+      if (ctxs[j] == c) { c0->err = "mk_merge_devices: the same context twice"; return MK_ERR_ARG; }
+  }
+  const auto t_begin = Clock::now();
+  const bool gather = (flags & MK_MERGE_GATHER) != 0;
+  const int m = gather ? 1 : n;  // owners
+  const int rw = mk_words_per_key(c0) + 1;
+  const bool packed = c0->mode != MK_MODE_BYREF;
+  int rc;
+  mk_merge_stats_t S;
+  memset(&S, 0, sizeof S);
+  S.contexts = n;
+  {
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i)
+      if (std::find(devs.begin(), devs.end(), ctxs[i]->device) == devs.end()) devs.push_back(ctxs[i]->device);
+    S.devices = (int)devs.size();
+  }
+  auto fail = [&](int i, int code) {
+    if (i > 0 && !ctxs[i]->err.empty()) c0->err = ctxs[i]->err;
+    return code;
+  };
+
+  // ---- owner bounds
+  u64 bounds[MK_MAX_OWNERS];
+  for (auto& b : bounds) b = ~0ull;
+  if (m > 1) {
+    const int key_bits = c0->mode == MK_MODE_HASH128 ? 64 : c0->bits * c0->k;
+    if ((rc = mk_owner_bounds(key_bits, m, (uint64_t*)bounds)) != MK_OK) return rc;
+    if ((flags & MK_MERGE_BALANCED) && (c0->mode == MK_MODE_HASH64 || c0->mode == MK_MODE_HASH128)) {
+      size_t total = 0;
+      for (int i = 0; i < n; ++i) {
+        if ((rc = mk_settle(ctxs[i])) != MK_OK) return fail(i, rc);
+        total += table_of(ctxs[i]).rows;
+      }
+      const size_t stride = std::max<size_t>(1, total / 16384);  // ~16 k keys in all, each context at the same rate
+      std::vector<std::vector<u64>> parts((size_t)n);
+      int bad = -1;
+      rc = on_every(n, [&](int i) { int r = sample_keys(ctxs[i], stride, parts[i]); if (r) bad = i; return r; });
+      if (rc) return fail(bad, rc);
+      std::vector<u64> all;
+      for (auto& p : parts) all.insert(all.end(), p.begin(), p.end());
+      if (all.size() >= (size_t)(8 * m)) {  // (fewer: keep the equal ranges)
+        std::sort(all.begin(), all.end());
+        for (int j = 1; j < m; ++j) bounds[j - 1] = all[all.size() * (size_t)j / (size_t)m];
+      }
+    }
+  }
+
+  // ---- phase A: text rows to the host, packed rows grouped by owner (the gathering context keeps its own table)
+  std::vector<std::vector<u64>> counts((size_t)n, std::vector<u64>((size_t)m, 0));
+  std::vector<std::vector<uint8_t>> ex_k((size_t)n);
+  std::vector<std::vector<uint64_t>> ex_c((size_t)n);
+  std::vector<u64> rows_before((size_t)n, 0);
+  const auto t_a = Clock::now();
+  {
+    int bad = -1;
+    rc = on_every(n, [&](int i) {
+      mk_ctx* c = ctxs[i];
+      int r;
+      if ((r = mk_settle(c)) != MK_OK) { bad = i; return r; }
+      rows_before[i] = table_of(c).kind == 3 ? 0 : table_of(c).rows;
+      if (gather && i == 0) return MK_OK;
+      if (c->run_ref_rows) {
+        size_t nr = 0;
+        if ((r = mk_export_exotic(c, nullptr, nullptr, 0, &nr)) != MK_OK) { bad = i; return r; }
+        ex_k[i].resize(nr * (size_t)c->k + 1);
+        ex_c[i].resize(nr + 1);
+        if ((r = mk_export_exotic(c, ex_k[i].data(), ex_c[i].data(), nr, &nr)) != MK_OK) { bad = i; return r; }
+        ex_c[i].resize(nr);
+      }
+      if (!packed) return MK_OK;
+      const TableRef t = table_of(c);
+      const size_t cap = (t.kind == 3 ? t.slots : t.rows) + 1;  // (the rows the host knows of, + the one key kept beside the table)
+      if (hipSetDevice(c->device) != hipSuccess) { bad = i; c->err = "hipSetDevice failed"; return MK_ERR_HIP; }
+      if ((r = mk_buf_reserve(c, c->xfer_out, cap * rw * sizeof(u64) + 64)) != MK_OK) { bad = i; return r; }
+      if ((r = bucket_rows(c, bounds, m, (u64*)c->xfer_out.p, cap, counts[i].data(), m - 1)) != MK_OK) { bad = i; return r; }
+      return MK_OK;
+    });
+    if (rc) return fail(bad, rc);
+  }
+  S.s_bucket = secs(t_a);
+  for (int i = 0; i < n; ++i) S.rows_in += rows_before[i] + (ctxs[i]->mode == MK_MODE_HASH64 && ctxs[i]->run_side ? 1 : 0);
+
+  // ---- phase B: empty the tables that are rebuilt, room for what arrives
+  std::vector<u64> recv((size_t)m, 0), own((size_t)n, 0);
+  std::vector<std::vector<u64>> recv_off((size_t)n, std::vector<u64>((size_t)m, 0));  // row offset of source i in owner j's receive buffer
+  for (int j = 0; j < m; ++j)
+    for (int i = 0; i < n; ++i) {
+      if (i == j && !(gather && i == 0)) { own[i] = counts[i][j]; continue; }
+      recv_off[i][j] = recv[j];
+      recv[j] += counts[i][j];
+    }
+  {
+    int bad = -1;
+    rc = on_every(n, [&](int i) {
+      mk_ctx* c = ctxs[i];
+      int r;
+      if (!(gather && i == 0) && (r = mk_reset(c)) != MK_OK) { bad = i; return r; }
+      if (i >= m) return MK_OK;
+      if (hipSetDevice(c->device) != hipSuccess) { bad = i; c->err = "hipSetDevice failed"; return MK_ERR_HIP; }
+      if (recv[i] && (r = mk_buf_reserve(c, c->xfer_in, (size_t)recv[i] * rw * sizeof(u64) + 64)) != MK_OK) { bad = i; return r; }
+      if ((own[i] + recv[i]) && (r = mk_grow_run(c, (size_t)(own[i] + recv[i]))) != MK_OK) { bad = i; return r; }
+      return MK_OK;
+    });
+    if (rc) return fail(bad, rc);
+  }
+
+  // ---- phase C: the segments travel (source i -> owner (i + s) mod n in round s: every pair of GPUs at once)
+  const auto t_c = Clock::now();
+  std::vector<hipEvent_t> sent((size_t)n, nullptr);
+  auto drop_events = [&] { for (auto& e : sent) if (e) { (void)hipEventDestroy(e); e = nullptr; } };
+  std::vector<char> sends((size_t)n, 0);
+  {
+    std::vector<std::pair<int, int>> pairs_seen;
+    for (int s = 1; s < n && rc == MK_OK; ++s)
+      for (int i = 0; i < n && rc == MK_OK; ++i) {
+        const int j = (i + s) % n;
+        if (j >= m || !counts[i][j]) continue;
+        mk_ctx* src = ctxs[i];
+        mk_ctx* dst = ctxs[j];
+        u64 seg = 0;
+        for (int q = 0; q < j; ++q) seg += counts[i][q];
+        const size_t bytes = (size_t)counts[i][j] * rw * sizeof(u64);
+        const u64* from = (const u64*)src->xfer_out.p + seg * (u64)rw;
+        u64* to = (u64*)dst->xfer_in.p + recv_off[i][j] * (u64)rw;
+        hipError_t e;
+        if (src->device != dst->device) {
+          const std::pair<int, int> pr(std::min(src->device, dst->device), std::max(src->device, dst->device));
+          if (std::find(pairs_seen.begin(), pairs_seen.end(), pr) == pairs_seen.end()) {
+            pairs_seen.push_back(pr);
+            S.peer_direct += enable_peer_pair(pr.first, pr.second);
+          }
+        }
+        if ((e = hipSetDevice(src->device)) == hipSuccess)
+          e = src->device == dst->device ? hipMemcpyAsync(to, from, bytes, hipMemcpyDeviceToDevice, src->stream)
+                                         : hipMemcpyPeerAsync(to, dst->device, from, src->device, bytes, src->stream);
+        if (e != hipSuccess) { c0->err = std::string("peer copy of table rows: ") + hipGetErrorString(e); rc = MK_ERR_HIP; break; }
+        sends[i] = 1;
+        S.rows_moved += counts[i][j];
+        S.bytes_moved += bytes;
+      }
+    for (int i = 0; i < n && rc == MK_OK; ++i) {
+      if (!sends[i]) continue;
+      hipError_t e = hipSetDevice(ctxs[i]->device);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&sent[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventRecord(sent[i], ctxs[i]->stream);
+      if (e != hipSuccess) { c0->err = std::string("event after the peer copies: ") + hipGetErrorString(e); rc = MK_ERR_HIP; }
+    }
+    // an owner's stream goes on only when every source that sent to it has
+    for (int j = 0; j < m && rc == MK_OK; ++j) {
+      if (hipSetDevice(ctxs[j]->device) != hipSuccess) { rc = MK_ERR_HIP; c0->err = "hipSetDevice failed"; break; }
+      for (int i = 0; i < n && rc == MK_OK; ++i) {
+        if (i == j || !counts[i][j] || !sent[i]) continue;
+        if (hipStreamWaitEvent(ctxs[j]->stream, sent[i], 0) != hipSuccess) { rc = MK_ERR_HIP; c0->err = "hipStreamWaitEvent failed"; }
+      }
+    }
+  }
+  if (rc) {
+    for (int i = 0; i < n; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+    drop_events();
+    return rc;
+  }
+
+  // ---- phase D: every owner insert-adds its own segment and what arrived; text rows into ctxs[0]
+  {
+    int bad = -1;
+    rc = on_every(n, [&](int j) {
+      mk_ctx* c = ctxs[j];
+      int r;
+      if (hipSetDevice(c->device) != hipSuccess) { bad = j; c->err = "hipSetDevice failed"; return MK_ERR_HIP; }
+      if (j < m && packed && (own[j] + recv[j])) {
+        if (hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream) != hipSuccess) { bad = j; c->err = "hipMemsetAsync failed"; return MK_ERR_HIP; }
+        if (own[j]) {
+          u64 seg = 0;
+          for (int q = 0; q < j; ++q) seg += counts[j][q];
+          if ((r = mk_launch_import_rows(c, (const uint64_t*)c->xfer_out.p + seg * (u64)rw, (size_t)own[j])) != MK_OK) { bad = j; return r; }
+        }
+        if (recv[j] && (r = mk_launch_import_rows(c, (const uint64_t*)c->xfer_in.p, (size_t)recv[j])) != MK_OK) { bad = j; return r; }
+        if ((r = mk_pull_info(c)) != MK_OK) { bad = j; return r; }
+        if (c->mode == MK_MODE_HASH128) c->run128_rows += (size_t)c->h_info->new_rows;
+        else if (c->mode == MK_MODE_HASH64) { c->run_rows += (size_t)c->h_info->new_rows; c->run_side += c->h_info->side; }
+      } else {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) { bad = j; c->err = "hipStreamSynchronize failed"; return MK_ERR_HIP; }
+      }
+      return MK_OK;
+    });
+    if (rc) {
+      for (int i = 0; i < n; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+      drop_events();
+      return fail(bad, rc);
+    }
+  }
+  // (the sources' copies are done: every owner has waited for them; a source that only sent waits here)
+  for (int i = 0; i < n; ++i) { (void)hipSetDevice(ctxs[i]->device); (void)hipStreamSynchronize(ctxs[i]->stream); }
+  drop_events();
+  S.s_copy = secs(t_c);
+  const auto t_d = Clock::now();
+  for (int i = 0; i < n; ++i)
+    if (!ex_c[i].empty() && (rc = mk_import_exotic(c0, ex_k[i].data(), ex_c[i].data(), ex_c[i].size())) != MK_OK) return rc;
+  S.s_import = secs(t_d);
+  for (int i = 0; i < n; ++i) {
+    const TableRef t = table_of(ctxs[i]);
+    const u64 r = (t.kind == 3 ? 0 : t.rows) + (ctxs[i]->mode == MK_MODE_HASH64 && ctxs[i]->run_side ? 1 : 0) + ctxs[i]->run_ref_rows;
+    S.rows_out += r;
+    S.max_owned = std::max<uint64_t>(S.max_owned, r);
+  }
+  S.s_total = secs(t_begin);
+  if (st) *st = S;
+  return MK_OK;
+}

@@ -549,6 +549,55 @@ int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_
   return MK_OK;
 }
 
+// Interleaved rows {key, count} / {hi, lo, count} / {bin, count}: the layout rows travel in between GPUs
+// (mk_multi.hip, mercat2_amd/dist.py), so that a row's words move side by side and are read with one access.
+__global__ void mk_import_rows64_k(const ulonglong2* __restrict__ rows2, size_t rows, MkSlot* __restrict__ run, u64 run_mask,
+                                   u64* __restrict__ new_rows, u64* __restrict__ side) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong2 r = rows2[i];
+    if (!r.y) continue;
+    if (r.x == MK_EMPTY) atomicAdd(side, r.y);
+    else fresh += upsert64(run, run_mask, r.x, r.y) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+__global__ void mk_import_rows128_k(const u64* __restrict__ rows3, size_t rows, MkSlot128* __restrict__ run, u64 run_mask,
+                                    u64* __restrict__ new_rows) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+    const u64 hi = rows3[3 * i], lo = rows3[3 * i + 1], cnt = rows3[3 * i + 2];
+    if (cnt) fresh += upsert128(run, run_mask, hi, lo, cnt) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+__global__ void mk_import_rows_bins_k(const ulonglong2* __restrict__ rows2, size_t rows, u64* __restrict__ bins, size_t nbins) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+    const ulonglong2 r = rows2[i];
+    if (r.x < nbins && r.y) atomicAdd(&bins[r.x], r.y);
+  }
+}
+
+int mk_launch_import_rows(mk_ctx* c, const uint64_t* d_rows, size_t rows) {
+  if (!rows) return MK_OK;
+  MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  if (c->mode == MK_MODE_DENSE) {
+    hipLaunchKernelGGL(mk_import_rows_bins_k, dim3(grid_for(rows)), dim3(256), 0, c->stream, (const ulonglong2*)d_rows, rows,
+                       (u64*)c->run.p, (size_t)1 << (c->bits * c->k));
+  } else if (c->mode == MK_MODE_HASH64) {
+    hipLaunchKernelGGL(mk_import_rows64_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const ulonglong2*)d_rows,
+                       rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows, &info->side);
+  } else if (c->mode == MK_MODE_HASH128) {
+    hipLaunchKernelGGL(mk_import_rows128_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_rows, rows,
+                       (MkSlot128*)c->run128.p, (u64)(c->run128_slots - 1), &info->new_rows);
+  } else {
+    c->err = "import of packed rows: the context has no packed table";
+    return MK_ERR_STATE;
+  }
+  MK_HIP(hipGetLastError());
+  return MK_OK;
+}
+
 int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows) {
   if (!rows) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;

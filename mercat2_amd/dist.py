@@ -78,12 +78,42 @@ def exchange_pairs(keys: torch.Tensor, counts: torch.Tensor, key_bits: int, grou
     return rows[:, 0].contiguous(), rows[:, 1].contiguous()
 
 
-def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0, always: bool = False) -> int:
+def balanced_bounds(ctx, key_bits: int, world: int, group=None, device=None, per_rank: int = 2048) -> List[int]:
+    """Owner bounds with about equal ROWS per owner (SURVEY 8e "sampled splitters"): every rank samples about
+    ``per_rank`` of its keys (mk_sample_keys: every stride-th slot of the hashed table), the samples are all-gathered
+    and cut at their quantiles.  Every rank computes the same bounds.  Real tables are far from uniform over the key
+    space (canonical keys start with A or C, GC skew, poly-A): with equal key ranges the slowest owner sets the step."""
+    rows = max(1, ctx.rows())
+    mine = ctx.sample_keys(max(1, rows // per_rank), cap=8 * per_rank)
+    dev = device if device is not None else torch.device("cuda", ctx.device)
+    if dev.type != "cpu" and dist.get_backend(group) == "gloo":
+        dev = torch.device("cpu")
+    cap = 8 * per_rank
+    buf = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    buf[0] = int(mine.size)
+    if mine.size:
+        buf[1:1 + mine.size] = torch.from_numpy(mine.view(np.int64)).to(dev)
+    got = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(got, buf, group=group)
+    parts = [g[1:1 + int(g[0].item())].cpu().numpy().view(np.uint64) for g in got]
+    allk = np.sort(np.concatenate(parts)) if parts else np.zeros(0, np.uint64)
+    if allk.size < 8 * world:
+        return range_bounds(key_bits, world)
+    return [int(allk[allk.size * i // world]) for i in range(1, world)]
+
+
+def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0, always: bool = False,
+                balanced: bool = False) -> int:
     """Re-partition ctx's running table across the ranks of `group` by key range and sum.
     On return ctx holds exactly the packed rows of its own range; rows kept as text (characters
     outside the alphabet, k > 64: rare) all sit on rank 0.  With ``min_count`` > 1 rows whose merged
     count is below it are dropped at their owner (single-chunk samples: the filter comes after the
-    merge).  Returns the number of rows this rank now owns."""
+    merge).  Returns the number of rows this rank now owns.
+
+    The rows are grouped by owner ON THE DEVICE in one histogram pass and one scatter pass over the table
+    (mk_bucket_rows_device: interleaved {key word(s), count} rows, owner after owner -- no sort, no torch.cat), sent
+    with one all_to_all_single, and insert-added at the owner (mk_import_rows_device).  ``balanced``: owner bounds
+    from sampled keys instead of equal key ranges.  Dense tables (k * bits <= 15) are ONE reduce of the bins to rank 0."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1 and not always:
@@ -91,24 +121,51 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
             ctx.filter_min(min_count)
         return ctx.rows()
     dev = device if device is not None else torch.device("cuda", ctx.device)
+    staged = dev.type != "cpu" and dist.get_backend(group) == "gloo"  # gloo moves host memory (test / rehearsal path)
+    mode = ctx.stats()["mode_name"]
     words = ctx.words_per_key()
-    packed = ctx.stats()["mode_name"] in ("dense", "hash64", "hash128")  # byref keeps every row as text
-    n = 0
-    cap = ctx.rows() + 1
-    keys = torch.empty((cap, words), dtype=torch.int64, device=dev)
-    cnts = torch.empty(cap, dtype=torch.int64, device=dev)
-    if packed:
-        n = ctx.export_pairs_device(keys.data_ptr(), cnts.data_ptr(), cap)
-    rows = torch.cat([keys[:n], cnts[:n, None]], dim=1)
-    ex_k, ex_c = ctx.export_exotic()
-    ctx.reset()
-    got, extras = exchange_rows(rows, 64 if words == 2 else key_bits, int(ex_c.size), group, always)
-    if got.shape[0]:
-        rk = got[:, :words].contiguous()
-        rc = got[:, words].contiguous()
-        if dev.type == "cuda":
-            torch.cuda.synchronize(dev)
-        ctx.import_pairs_device(rk.data_ptr(), rc.data_ptr(), got.shape[0])
+    ex_k, ex_c = ctx.export_exotic()  # (nothing but a size query when the context holds no text rows)
+    if mode == "dense":
+        nbins = 1 << ((2 if ctx.alphabet == 0 else 5) * ctx.k)
+        bins = torch.empty(nbins, dtype=torch.int64, device=dev)
+        ctx.dense_bins_device(bins.data_ptr(), nbins, False)
+        if staged:
+            host = bins.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=group)
+            bins.copy_(host)
+        else:
+            dist.reduce(bins, dst=0, op=dist.ReduceOp.SUM, group=group)
+        _wait_current_stream(dev)
+        ctx.reset()
+        if rank == 0:
+            ctx.dense_bins_device(bins.data_ptr(), nbins, True)
+        extras = _all_extras(int(ex_c.size), world, dev if not staged else torch.device("cpu"), group)
+    else:
+        packed = mode in ("hash64", "hash128")  # byref keeps every row as text
+        bits = 64 if words == 2 else key_bits
+        bounds = (balanced_bounds(ctx, bits, world, group, dev) if (balanced and packed) else range_bounds(bits, world))
+        cap = ctx.rows() + 1
+        rows = torch.empty((cap, words + 1), dtype=torch.int64, device=dev)
+        send_l = ctx.bucket_rows_device(bounds, rows.data_ptr(), cap) if packed else [0] * world
+        ctx.reset()
+        meta_dev = torch.device("cpu") if staged else dev
+        meta = torch.tensor([[n, int(ex_c.size)] for n in send_l], dtype=torch.int64, device=meta_dev)
+        got_meta = torch.empty_like(meta)
+        dist.all_to_all_single(got_meta, meta, group=group)
+        got_meta = got_meta.cpu()
+        recv_l = got_meta[:, 0].tolist()
+        extras = [int(x) for x in got_meta[:, 1].tolist()]
+        n_send, n_recv = int(sum(send_l)), int(sum(recv_l))
+        if staged:
+            out_h = torch.empty((n_recv, words + 1), dtype=torch.int64)
+            dist.all_to_all_single(out_h, rows[:n_send].cpu(), recv_l, send_l, group=group)
+            out = out_h.to(dev)
+        else:
+            out = torch.empty((n_recv, words + 1), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(out, rows[:n_send], recv_l, send_l, group=group)
+        if n_recv:
+            _wait_current_stream(dev)  # the rows have arrived before the engine's own stream reads them
+            ctx.import_rows_device(out.data_ptr(), n_recv)
     # rows kept as text: gathered (as objects, through the host) to rank 0 only when some rank has any
     if any(extras):
         gathered = [None] * world if rank == 0 else None
@@ -123,6 +180,19 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
     if min_count > 1:
         ctx.filter_min(min_count)
     return ctx.rows()
+
+
+def _wait_current_stream(dev) -> None:
+    """Host-wait for torch's current stream on ``dev`` only (the collective just issued), not for the whole device."""
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def _all_extras(extra: int, world: int, dev, group) -> List[int]:
+    t = torch.tensor([extra], dtype=torch.int64, device=dev)
+    got = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(got, t, group=group)
+    return [int(g.item()) for g in got]
 
 
 def record_ranges(text, parts: int) -> List[Tuple[int, int]]:

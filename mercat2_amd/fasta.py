@@ -14,7 +14,7 @@ import os
 import re
 import textwrap
 from pathlib import Path
-from typing import Dict, Tuple
+from typing import Optional, Dict, Tuple
 
 from . import native
 from .kmers import read_fasta_bytes
@@ -83,16 +83,24 @@ def clean_text(raw, toupper: bool = False) -> Tuple[bytes, Dict[str, float]]:
     return cleaned, {"GC Content": 100.0 * st["gc_count"] / st["total_length"]}
 
 
-def removeN_text(fasta: Path, outpath: Path, toupper: bool):
+def removeN_text(fasta: Path, outpath: Path, toupper: bool, timings: Optional[dict] = None):
     """removeN that also hands back the cleaned text: ``(path, stats, cleaned bytes)`` -- the counting path takes
-    the bytes from memory instead of inflating the file it has just written."""
+    the bytes from memory instead of inflating the file it has just written.  ``timings`` receives read_s / clean_s /
+    gzip_s (the CLI's -debug line)."""
+    import timeit
     os.makedirs(outpath, exist_ok=True)
     basename = Path(fasta).stem.split(".")[0]
     out_fasta = Path(outpath, f"{basename}_clean.fna.gz")
-    cleaned, stats = clean_text(read_fasta_bytes(fasta), toupper)
+    t0 = timeit.default_timer()
+    raw = read_fasta_bytes(fasta)
+    t1 = timeit.default_timer()
+    cleaned, stats = clean_text(raw, toupper)
+    t2 = timeit.default_timer()
     with gzip.open(out_fasta, "wb") as writer:
         writer.write(cleaned)
         writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
+    if timings is not None:
+        timings.update(read_s=t1 - t0, clean_s=t2 - t1, gzip_s=timeit.default_timer() - t2)
     return out_fasta.absolute(), stats, cleaned
 
 

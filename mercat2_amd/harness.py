@@ -77,6 +77,34 @@ def _drain_pool() -> None:
         _POOL.clear()
 
 
+def _device_list(device: int, devices: Optional[Sequence[int]]) -> List[int]:
+    """The GPUs a sample may use: ``devices`` when given (several: its chunks are spread over them), else ``device``."""
+    if devices:
+        return [int(d) for d in devices]
+    return [int(device)]
+
+
+def _take_contexts(kmer: int, alphabet: int, devs: Sequence[int], streams: int, canon: bool, limit: int) -> List[native.Counter]:
+    """Contexts in the order mk_count_file wants them (native.plan_contexts): chunk i -> device devs[i mod ndev],
+    the chunks of a device taking turns on its ``streams`` contexts; at most ``limit`` contexts (chunks of the sample)."""
+    order = native.plan_contexts(list(devs), max(1, int(streams)))[: max(1, limit)]
+    return [_take_context(kmer, alphabet, d, canon) for d in order]
+
+
+def _sum_into_first(ctxs: Sequence[native.Counter]) -> None:
+    """The contexts of one GPU are summed on that GPU, then the GPUs' tables go to ctxs[0] (mk_merge_devices)."""
+    leaders = []
+    for c in ctxs:
+        lead = next((x for x in leaders if x.device == c.device), None)
+        if lead is None:
+            leaders.append(c)
+        else:
+            lead.merge_from(c)
+            c.reset()
+    if len(leaders) > 1:
+        native.merge_devices(leaders, native.MERGE_GATHER)
+
+
 def _finish(ctx: native.Counter, basename: str, out_file, report=print) -> Tuple[str, Optional[os.PathLike]]:
     rows = ctx.write_tsv(out_file, basename)
     if rows:
@@ -100,12 +128,15 @@ def run_mercat2(basename: str, files: Sequence, out_file, kmer: int, min_count: 
 
 
 def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib: int = 100, chunked: bool = False,
-             *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, report=print,
-             keep: Optional[dict] = None, alphabet: Optional[int] = None) -> Tuple[str, Optional[os.PathLike]]:
+             *, device: int = 0, devices: Optional[Sequence[int]] = None, streams: Optional[int] = None, canonical: bool = False,
+             report=print, keep: Optional[dict] = None, alphabet: Optional[int] = None,
+             timings: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
     """run_sample for FASTA bytes already in memory (e.g. the text removeN just produced, mercat2_amd.fasta):
     ``chunked`` says whether the reference would have chunked the file these bytes stand for (its on-disk size
     against -s, bin/mercat2.py:101); if so the Chunker's cut rule is applied to the bytes and every chunk is
-    counted with its own min_count filter, the chunks dealt to ``streams`` contexts."""
+    counted with its own min_count filter, the chunks dealt to ``streams`` contexts on each of ``devices``
+    (chunk i -> device i mod N) and the tables summed into the first context."""
+    import timeit
     from concurrent.futures import ThreadPoolExecutor
     from .chunker import chunk_offsets
     mv = memoryview(text)
@@ -116,11 +147,12 @@ def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib
     spans = list(zip(offs[:-1], offs[1:]))
     if streams is None:
         streams = native.default_streams(kmer, alphabet)
-    n = max(1, min(int(streams), len(spans)))
     canon = bool(canonical and alphabet == native.ALPHABET_NT2)
-    key = (kmer, alphabet, device, canon)
-    ctxs = [_take_context(*key) for _ in range(n)]
+    devs = _device_list(device, devices)
+    ctxs = _take_contexts(kmer, alphabet, devs, streams, canon, len(spans))
+    n = len(ctxs)
     size = 1 << 62
+    t0 = timeit.default_timer()
     try:
         def share(i):
             for a, b in spans[i::n]:
@@ -130,10 +162,12 @@ def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib
         else:
             with ThreadPoolExecutor(n) as pool:
                 list(pool.map(share, range(n)))
-            for c in ctxs[1:]:
-                ctxs[0].merge_from(c)
+            _sum_into_first(ctxs)
         size = len(mv)
+        t1 = timeit.default_timer()
         result = _finish(ctxs[0], basename, out_file, report)
+        if timings is not None:
+            timings.update(count_s=t1 - t0, tsv_s=timeit.default_timer() - t1, chunks=len(spans), contexts=n, devices=len(set(devs[:n])))
         if keep is not None and result[1] is not None:
             ctxs[0].trim()
             keep[basename] = ctxs.pop(0)
@@ -143,19 +177,27 @@ def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib
         raise
     finally:
         for c in ctxs:
-            _give_back(c, key, size)
+            _give_back(c, (kmer, alphabet, c.device, canon), size)
+
+
+# a file that is ONE filter unit is only spread over several GPUs from this size on (mk_count_file: MK_SPLIT_MIN)
+SPLIT_MIN_BYTES = 64 << 20
 
 
 def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_mib: int = 100,
-               *, device: int = 0, streams: Optional[int] = None, canonical: bool = False, threads: int = 0,
-               stats: Optional[dict] = None, report=print, keep: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
+               *, device: int = 0, devices: Optional[Sequence[int]] = None, streams: Optional[int] = None, canonical: bool = False,
+               threads: int = 0, stats: Optional[dict] = None, report=print, keep: Optional[dict] = None,
+               timings: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
     """chunk_files + run_mercat2 in one step with no chunk files (mk_count_file): native reader
     threads read (inflate) the file once into pinned blocks, the reference's cut rule is applied to
     the stream, and each chunk is copied to the GPU and counted (filtered on its own) while the next
     one is being read.  Same TSV as the two-step path.
 
-    ``streams`` contexts (HIP streams; default native.default_streams) take the chunks in turn and count concurrently; they are
-    summed on the device at the end.  ``threads`` = reader threads for plain files (0: pick).
+    ``streams`` contexts (HIP streams; default native.default_streams) per GPU take the chunks in turn and count
+    concurrently; they are summed on the device at the end.  With several ``devices`` chunk i goes to device i mod N
+    (the Ray fan-out of bin/mercat2.py:119-120 with GPUs for workers) and the GPUs' tables are summed into the first
+    by peer copies (mk_merge_devices); a file that is one filter unit but large is cut at record starts, counted
+    unfiltered on all of them and filtered after the sum.  ``threads`` = reader threads for plain files (0: pick).
     ``canonical`` is the opt-in extension of mk_set_canonical (not reference behaviour).  If a dict
     is passed as ``stats`` it receives the mk_file_stats_t fields of the read.  ``report`` receives
     the one line the reference prints per sample.  With a dict as ``keep`` the sample's table stays
@@ -166,17 +208,29 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
     alphabet = guess_alphabet(file, read_head(file))
     if streams is None:
         streams = native.default_streams(kmer, alphabet)
-    n = max(1, int(streams)) if chunked else 1
     canon = bool(canonical and alphabet == native.ALPHABET_NT2)
-    key = (kmer, alphabet, device, canon)
-    ctxs = [_take_context(*key) for _ in range(n)]
+    devs = _device_list(device, devices)
+    disk = os.stat(file).st_size
+    spread = chunked or (len(devs) > 1 and disk >= SPLIT_MIN_BYTES // (4 if str(file).endswith(".gz") else 1))
+    if not spread:
+        devs = devs[:1]
+    limit = len(devs) * max(1, int(streams)) if spread else 1
+    if chunked and chunk_bytes:
+        limit = min(limit, max(1, -(-disk * (4 if str(file).endswith(".gz") else 1) // chunk_bytes)))
+    ctxs = _take_contexts(kmer, alphabet, devs, streams if spread else 1, canon, limit)
     text_bytes = 1 << 62
+    import timeit
+    t0 = timeit.default_timer()
     try:
         st = native.count_file(ctxs, file, chunk_bytes, min_count, threads)
         text_bytes = st["text_bytes"]
         if stats is not None:
             stats.update(st)
+        t1 = timeit.default_timer()
         result = _finish(ctxs[0], basename, out_file, report)
+        if timings is not None:
+            timings.update(count_s=t1 - t0, tsv_s=timeit.default_timer() - t1, chunks=st["chunks"], contexts=st["contexts"],
+                           devices=st["devices"], merge_s=st["s_merge"], wait_io_s=st["s_wait_io"], split_pieces=st["split_pieces"])
         if keep is not None and result[1] is not None:
             ctxs[0].trim()
             keep[basename] = ctxs.pop(0)
@@ -186,4 +240,4 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
         raise
     finally:
         for c in ctxs:
-            _give_back(c, key, text_bytes)
+            _give_back(c, (kmer, alphabet, c.device, canon), text_bytes)

@@ -29,7 +29,12 @@ ABI_SYMBOLS = [
     "mk_chunk_cuts", "mk_synth_reads", "mk_version", "mk_count_file", "mk_stream_cuts",
     "mk_merged_export", "mk_write_merged_tsv", "mk_trim", "mk_alpha_stats", "mk_gunzip", "mk_crc32_of", "mk_gunzip_parallel",
     "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t", "mk_write_merged_tsv_as_reference",
+    "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
+    "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
+    "mk_device_count",
 ]
+MK_ABI = 3  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
+MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED = 0, 1, 2
 
 
 class MercatHipError(RuntimeError):
@@ -58,8 +63,18 @@ class Stats(C.Structure):
 class FileStats(C.Structure):
     """mk_file_stats_t (include/mercat_hip.h)."""
     _fields_ = ([(n, C.c_uint64) for n in ("disk_bytes", "text_bytes", "chunks")] +
-                [(n, C.c_int32) for n in ("gz", "chunked", "members", "threads", "contexts", "pad_")] +
-                [(n, C.c_double) for n in ("s_wait_io", "s_wait_gpu", "s_total")])
+                [(n, C.c_int32) for n in ("gz", "chunked", "members", "threads", "contexts", "devices", "split_pieces", "pad_")] +
+                [(n, C.c_double) for n in ("s_wait_io", "s_wait_gpu", "s_total", "s_merge")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
+
+
+class MergeStats(C.Structure):
+    """mk_merge_stats_t (include/mercat_hip.h)."""
+    _fields_ = ([(n, C.c_uint64) for n in ("rows_in", "rows_out", "rows_moved", "bytes_moved", "max_owned")] +
+                [(n, C.c_int32) for n in ("contexts", "devices", "peer_direct", "pad_")] +
+                [(n, C.c_double) for n in ("s_bucket", "s_copy", "s_import", "s_total")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
@@ -137,7 +152,28 @@ def lib() -> C.CDLL:
         "mk_crc32_of": (C.c_uint32, [u8p, C.c_size_t, C.c_uint32]),
         "mk_gunzip": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "mk_stream_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
+        "mk_record_cuts": (C.c_int, [u8p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, C.c_size_t, szp]),
+        "mk_owner_bounds": (C.c_int, [C.c_int, C.c_int, u64p]),
+        "mk_plan_contexts": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "mk_bucket_rows_device": (C.c_int, [vp, u64p, C.c_int, u64p, C.c_size_t, u64p]),
+        "mk_import_rows_device": (C.c_int, [vp, u64p, C.c_size_t]),
+        "mk_merge_devices": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(MergeStats)]),
+        "mk_device_count": (C.c_int, []),
+        "mk_sample_keys": (C.c_int, [vp, C.c_size_t, u64p, C.c_size_t, szp]),
+        "mk_dense_bins_device": (C.c_int, [vp, u64p, C.c_size_t, C.c_int]),
+        "mk_export_size_multi": (C.c_int, [C.POINTER(vp), C.c_int, szp]),
+        "mk_export_multi": (C.c_int, [C.POINTER(vp), C.c_int, u8p, u64p, C.c_size_t]),
+        "mk_write_tsv_multi": (C.c_int, [C.POINTER(vp), C.c_int, C.c_char_p, C.c_char_p, szp]),
     }
+    L.mk_version.restype = C.c_char_p
+    ver = (L.mk_version() or b"").decode()
+    try:
+        abi = int(ver.split()[1].split(".")[0])
+    except (IndexError, ValueError):
+        abi = -1
+    if abi != MK_ABI:
+        raise MercatHipError(-4, "%s announces '%s' but this binding is written for ABI %d: rebuild the library "
+                                 "(make -C mercat2_amd/csrc) -- struct layouts would not match" % (path, ver, MK_ABI))
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
@@ -252,10 +288,94 @@ def stream_cuts(text, chunksize: int, block: int) -> np.ndarray:
         cap = need.value
 
 
+def record_cuts(text, piece: int, block: int = 1 << 20) -> np.ndarray:
+    """Where mk_count_file cuts one filter unit that it spreads over several GPUs (mk_record_cuts): pieces of at
+    least ``piece`` bytes that end where a record starts."""
+    L = lib()
+    addr, n, keep = _buf_ptr(text)
+    need = C.c_size_t(0)
+    cap = 64
+    while True:
+        cuts = np.empty(cap, dtype=np.uint64)
+        rc = L.mk_record_cuts(addr, n, int(piece), int(block), cuts.ctypes.data, cap, C.byref(need))
+        if rc == MK_OK:
+            return cuts[: need.value].copy()
+        if rc != -7:
+            raise MercatHipError(rc, "mk_record_cuts")
+        cap = need.value
+
+
+def device_count() -> int:
+    """HIP devices this process sees (mk_device_count)."""
+    return int(lib().mk_device_count())
+
+
+def owner_bounds(key_bits: int, n: int) -> list:
+    """mk_owner_bounds: first key of owner 1..n-1 when [0, 2^key_bits) is cut into n equal ranges."""
+    out = np.zeros(max(1, n - 1), dtype=np.uint64)
+    rc = lib().mk_owner_bounds(int(key_bits), int(n), out.ctypes.data)
+    if rc:
+        raise MercatHipError(rc, "mk_owner_bounds")
+    return [int(x) for x in out[: n - 1]]
+
+
+def plan_contexts(devices: Sequence[int], streams: int) -> list:
+    """mk_plan_contexts: device of every context, in creation order, so that mk_count_file's "chunk i -> ctxs[i mod
+    nctx]" means device devices[i mod ndev] with the chunks of a device taking turns on its streams."""
+    nd = len(devices)
+    arr = (C.c_int * nd)(*[int(d) for d in devices])
+    out = (C.c_int * (nd * int(streams)))()
+    rc = lib().mk_plan_contexts(arr, nd, int(streams), out)
+    if rc:
+        raise MercatHipError(rc, "mk_plan_contexts")
+    return list(out)
+
+
+def _ctx_array(ctxs: Sequence["Counter"]):
+    return (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+
+
+def merge_devices(ctxs: Sequence["Counter"], flags: int = MERGE_RANGES) -> dict:
+    """mk_merge_devices: sum the running tables of contexts on several GPUs (or several on one) in this process.
+    MERGE_RANGES: ctxs[i] ends up with key range i; MERGE_GATHER: everything in ctxs[0]."""
+    st = MergeStats()
+    rc = lib().mk_merge_devices(_ctx_array(ctxs), len(ctxs), int(flags), C.byref(st))
+    if rc:
+        ctxs[0]._check(rc)
+    return st.as_dict()
+
+
+def rows_multi(ctxs: Sequence["Counter"]) -> int:
+    n = C.c_size_t(0)
+    rc = lib().mk_export_size_multi(_ctx_array(ctxs), len(ctxs), C.byref(n))
+    if rc:
+        ctxs[0]._check(rc)
+    return n.value
+
+
+def export_multi(ctxs: Sequence["Counter"]) -> Tuple[np.ndarray, np.ndarray]:
+    """mk_export_multi: the sorted table of contexts that hold ascending key ranges (after MERGE_RANGES)."""
+    rows = rows_multi(ctxs)
+    kmers = np.empty((rows, ctxs[0].k), dtype=np.uint8)
+    counts = np.empty(rows, dtype=np.uint64)
+    rc = lib().mk_export_multi(_ctx_array(ctxs), len(ctxs), kmers.ctypes.data, counts.ctypes.data, rows)
+    if rc:
+        ctxs[0]._check(rc)
+    return kmers, counts
+
+
+def write_tsv_multi(ctxs: Sequence["Counter"], path, basename: str) -> int:
+    n = C.c_size_t(0)
+    rc = lib().mk_write_tsv_multi(_ctx_array(ctxs), len(ctxs), os.fsencode(str(path)), basename.encode(), C.byref(n))
+    if rc:
+        ctxs[0]._check(rc)
+    return n.value
+
+
 def count_file(ctxs: Sequence["Counter"], path, chunk_bytes: int, min_count: int, threads: int = 0) -> dict:
     """mk_count_file: read (inflate) ``path``, apply the Chunker rule iff its on-disk size is >=
-    chunk_bytes > 0, count every chunk with its own min_count filter on the contexts in turn and leave
-    the sum in ctxs[0].  Returns the mk_file_stats_t fields."""
+    chunk_bytes > 0, count every chunk with its own min_count filter on the contexts in turn (they may sit on
+    several GPUs: plan_contexts) and leave the sum in ctxs[0].  Returns the mk_file_stats_t fields."""
     L = lib()
     arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
     st = FileStats()
@@ -418,6 +538,29 @@ class Counter:
 
     def import_pairs_device(self, keys_ptr: int, counts_ptr: int, rows: int):
         self._check(self._L.mk_import_pairs_device(self._h, keys_ptr, counts_ptr, rows))
+
+    def bucket_rows_device(self, bounds: Sequence[int], rows_ptr: int, cap_rows: int) -> list:
+        """mk_bucket_rows_device: the table's rows grouped by owner (len(bounds)+1 owners) as interleaved
+        {key word(s), count} rows in the device buffer at rows_ptr; returns the rows per owner."""
+        n = len(bounds) + 1
+        b = np.array(list(bounds) + [0], dtype=np.uint64)
+        counts = np.zeros(n, dtype=np.uint64)
+        self._check(self._L.mk_bucket_rows_device(self._h, b.ctypes.data, n, rows_ptr, int(cap_rows), counts.ctypes.data))
+        return [int(x) for x in counts]
+
+    def sample_keys(self, stride: int, cap: int = 1 << 16) -> np.ndarray:
+        """About one in ``stride`` rows: the first word of their keys (mk_sample_keys), uint64, in no order."""
+        out = np.empty(cap, dtype=np.uint64)
+        n = C.c_size_t(0)
+        self._check(self._L.mk_sample_keys(self._h, int(max(1, stride)), out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def dense_bins_device(self, bins_ptr: int, nbins: int, store: bool):
+        """Dense mode: copy the bins out to / in from a device buffer (mk_dense_bins_device)."""
+        self._check(self._L.mk_dense_bins_device(self._h, bins_ptr, int(nbins), 1 if store else 0))
+
+    def import_rows_device(self, rows_ptr: int, rows: int):
+        self._check(self._L.mk_import_rows_device(self._h, rows_ptr, int(rows)))
 
     def words_per_key(self) -> int:
         """64-bit words per packed key in export_pairs_device / import_pairs_device (mk_words_per_key)."""

@@ -203,6 +203,74 @@ def test_bench_launches_ranks_and_strong_rows_match(tmp_path):
     assert two["also"]["scaling"] == "weak" and two["also"]["rows"] >= one["rows"]
 
 
+def test_bench_single_process_drives_several_gpus(tmp_path):
+    """`bench.py --gpus 2 --single-process`: ONE process, the C ABI's mk_merge_devices (rehearsal: both "GPUs" are
+    device 0).  Strong scaling ends with the rows of the 1-GPU run; weak (timed after it) with at least as many."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    common = ["--steps", "1", "--warmup", "0", "--no-cpu", "--no-file-leg", "--no-configs", "--reads", "2000000", "--genome", "1000000"]
+    env = dict(os.environ, MK_BENCH_SHARE_DEVICE="1")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+
+    def run(extra):
+        p = subprocess.run([sys.executable, str(ROOT / "bench.py")] + common + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout
+        return json.loads(lines[0])
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--single-process", "--scaling", "strong"])
+    assert two["n_gpus"] == 2 and two["single_process"] and not two["rccl"] and two["scaling"] == "strong"
+    assert two["rows"] == one["rows"] > 0
+    assert two["merge_devices"]["contexts"] == 2 and two["merge_devices"]["rows_out"] == one["rows"]
+    assert two["also"]["scaling"] == "weak" and two["also"]["rows"] >= one["rows"]
+
+
+def _worker_balanced(rank, port, k, c, out):
+    import torch
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        from mercat2_amd import native
+        from mercat2_amd.dist import merge_ranks
+        data = _data()
+        with native.Counter(k, native.ALPHABET_NT2, device=0, canonical=True) as ctx:
+            for a, b in _chunks(data)[rank::WORLD]:
+                ctx.count_chunk(memoryview(data)[a:b], c)
+            merge_ranks(ctx, 2 * k, device=torch.device("cuda", 0), balanced=True)
+            kmers, counts = ctx.export()
+        out[rank] = (kmers, counts)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,c", [(31, 2), (63, 1)])
+def test_sampled_splitters_share_canonical_rows_evenly(k, c):
+    """Canonical keys crowd the low end of the key space (min(key, revcomp) starts with A or C): with sampled owner
+    bounds (merge_ranks(balanced=True)) both ranks end up with about half of the rows, and the table is unchanged."""
+    from mercat2_amd import native
+    data = _data()
+    with native.Counter(k, native.ALPHABET_NT2, canonical=True) as ctx:
+        for a, b in _chunks(data):
+            ctx.count_chunk(memoryview(data)[a:b], c)
+        want_k, want_c = ctx.export()
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_worker_balanced, args=(port, k, c, out), nprocs=WORLD, join=True)
+        parts = [out[r] for r in range(WORLD)]
+    keys = np.concatenate([p[0].reshape(-1, k).view("S%d" % k).reshape(-1) for p in parts])
+    cnts = np.concatenate([p[1] for p in parts])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(keys[order], want_k.view("S%d" % k).reshape(-1))
+    assert np.array_equal(cnts[order], want_c)
+    share = parts[0][1].size / max(1, cnts.size)
+    assert 0.40 < share < 0.60, share
+
+
 # ------------------------------------------------------------------------------- the RCCL backend itself
 _RCCL_SCRIPT = r"""
 import os, sys
