@@ -365,7 +365,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   // ---- owner bounds
   u64 bounds[MK_MAX_OWNERS];
   for (auto& b : bounds) b = ~0ull;
-  if (m > 1) {
+  if (m > 1 && packed) {
     const int key_bits = c0->mode == MK_MODE_HASH128 ? 64 : c0->bits * c0->k;
     if ((rc = mk_owner_bounds(key_bits, m, (uint64_t*)bounds)) != MK_OK) return rc;
     if ((flags & MK_MERGE_BALANCED) && (c0->mode == MK_MODE_HASH64 || c0->mode == MK_MODE_HASH128)) {
@@ -400,7 +400,13 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
       mk_ctx* c = ctxs[i];
       int r;
       if ((r = mk_settle(c)) != MK_OK) { bad = i; return r; }
-      rows_before[i] = table_of(c).kind == 3 ? 0 : table_of(c).rows;
+      if (table_of(c).kind == 3) {  // dense bins: the rows are the bins that are not zero (tiny: counted on the host)
+        size_t r0 = 0;
+        if ((r = mk_export_size(c, &r0)) != MK_OK) { bad = i; return r; }
+        rows_before[i] = r0 - c->run_ref_rows;
+      } else {
+        rows_before[i] = table_of(c).rows;
+      }
       if (gather && i == 0) return MK_OK;
       if (c->run_ref_rows) {
         size_t nr = 0;
@@ -541,8 +547,8 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
     if (!ex_c[i].empty() && (rc = mk_import_exotic(c0, ex_k[i].data(), ex_c[i].data(), ex_c[i].size())) != MK_OK) return rc;
   S.s_import = secs(t_d);
   for (int i = 0; i < n; ++i) {
-    const TableRef t = table_of(ctxs[i]);
-    const u64 r = (t.kind == 3 ? 0 : t.rows) + (ctxs[i]->mode == MK_MODE_HASH64 && ctxs[i]->run_side ? 1 : 0) + ctxs[i]->run_ref_rows;
+    size_t r = 0;
+    if ((rc = mk_export_size(ctxs[i], &r)) != MK_OK) return fail(i, rc);
     S.rows_out += r;
     S.max_owned = std::max<uint64_t>(S.max_owned, r);
   }
