@@ -220,10 +220,18 @@ extern "C" void mk_destroy(mk_ctx* c) {
   delete c;
 }
 
-extern "C" int mk_reset(mk_ctx* c) {
+// expect_rows != 0: the packed table is also SIZED for about that many distinct keys when that is less than it has now
+// (never more: growing is what the imports do) -- after a merge across GPUs an owner keeps 1/N of the rows, and a table
+// that fits the caches takes the imports several times faster than the sample-sized one it had
+static int reset_impl(mk_ctx* c, size_t expect_rows) {
   if (!c) return MK_ERR_ARG;
   MK_HIP(hipSetDevice(c->device));
   if (c->pending_rows) { MK_HIP(hipStreamSynchronize(c->stream)); c->pending_rows = false; }
+  if (expect_rows && c->mode != MK_MODE_DENSE) {
+    const size_t want = pow2_at_least(4 * expect_rows);
+    if (c->run_slots > want) c->run_slots = want;
+    if (c->run128_slots > want) c->run128_slots = want;
+  }
   if (c->mode == MK_MODE_DENSE) {
     MK_HIP(hipMemsetAsync(c->run.p, 0, c->run_slots * sizeof(u64), c->stream));
   } else if (c->run_slots) {
@@ -245,6 +253,8 @@ extern "C" int mk_reset(mk_ctx* c) {
   MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
 }
+extern "C" int mk_reset(mk_ctx* c) { return reset_impl(c, 0); }
+extern "C" int mk_reset_for(mk_ctx* c, uint64_t expect_rows) { return reset_impl(c, (size_t)(expect_rows ? expect_rows : 1)); }
 
 extern "C" int mk_set_canonical(mk_ctx* c, int on) {
   if (!c) return MK_ERR_ARG;

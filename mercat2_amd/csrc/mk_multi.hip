@@ -16,7 +16,12 @@
 #include "mk_device.h"
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #define MK_MAX_OWNERS 64
@@ -121,6 +126,18 @@ __global__ __launch_bounds__(256) void mk_owner_scatter_k(V v, size_t slots, con
   }
 }
 
+// cursor[j] = first row of owner j's segment (exclusive prefix of the histogram): on the device, so that the host
+// waits once for histogram, prefix and scatter together
+__global__ void mk_owner_prefix_k(const u64* __restrict__ hist, u64* __restrict__ cursor, int n) {
+  if (threadIdx.x == 0) {
+    u64 at = 0;
+    for (int j = 0; j < MK_MAX_OWNERS; ++j) {
+      cursor[j] = at;
+      if (j < n) at += hist[j];
+    }
+  }
+}
+
 // first key words of the rows in every stride-th slot (the table is hashed: a uniform sample of its rows)
 template <class V>
 __global__ void mk_sample_keys_k(V v, size_t slots, size_t stride, u64* __restrict__ out, u64 cap, u64* __restrict__ cursor) {
@@ -166,10 +183,12 @@ static int bucket_rows(mk_ctx* c, const u64* bounds, int n, u64* d_rows, size_t 
   if ((rc = mk_settle(c)) != MK_OK) return rc;
   const TableRef t = table_of(c);
   const bool side = c->mode == MK_MODE_HASH64 && c->run_side != 0;
+  const int rw = mk_words_per_key(c) + 1;
   if (t.kind && t.rows) {
     if ((rc = reserve_meta(c)) != MK_OK) return rc;
     u64* d_bounds = (u64*)c->xfer_meta.p;
     u64* d_hist = d_bounds + MK_MAX_OWNERS;
+    u64* d_cursor = d_hist + MK_MAX_OWNERS;
     u64 hb[MK_MAX_OWNERS];
     for (int j = 0; j < MK_MAX_OWNERS; ++j) hb[j] = j + 1 < n ? bounds[j] : ~0ull;
     MK_HIP(hipMemcpyAsync(d_bounds, hb, sizeof hb, hipMemcpyHostToDevice, c->stream));
@@ -178,40 +197,37 @@ static int bucket_rows(mk_ctx* c, const u64* bounds, int n, u64* d_rows, size_t 
     if (t.kind == 1) hipLaunchKernelGGL(mk_owner_hist_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
     else if (t.kind == 2) hipLaunchKernelGGL(mk_owner_hist_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
     else hipLaunchKernelGGL(mk_owner_hist_k<ViewDense>, dim3(grid), dim3(256), 0, c->stream, ViewDense{(const u64*)t.p}, t.slots, (const u64*)d_bounds, n, d_hist);
+    if (d_rows) {  // (the scatter never writes past cap_rows; whether everything fitted is checked below)
+      hipLaunchKernelGGL(mk_owner_prefix_k, dim3(1), dim3(64), 0, c->stream, (const u64*)d_hist, d_cursor, n);
+      if (t.kind == 1) hipLaunchKernelGGL(mk_owner_scatter_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+      else if (t.kind == 2) hipLaunchKernelGGL(mk_owner_scatter_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+      else hipLaunchKernelGGL(mk_owner_scatter_k<ViewDense>, dim3(grid), dim3(256), 0, c->stream, ViewDense{(const u64*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
+    }
     MK_HIP(hipGetLastError());
     u64 hh[MK_MAX_OWNERS];
     MK_HIP(hipMemcpyAsync(hh, d_hist, sizeof hh, hipMemcpyDeviceToHost, c->stream));
     MK_HIP(hipStreamSynchronize(c->stream));
     for (int j = 0; j < n; ++j) counts[j] = hh[j];
   }
-  if (side) counts[side_owner] += 1;
-  if (!d_rows) return MK_OK;
-  u64 total = 0;
+  u64 total = side ? 1 : 0;
   for (int j = 0; j < n; ++j) total += counts[j];
-  if (total > cap_rows) { c->err = "rows by owner: buffer of " + std::to_string(cap_rows) + " rows is too small for " + std::to_string(total); return MK_ERR_RANGE; }
-  const int rw = mk_words_per_key(c) + 1;
-  if (t.kind && t.rows) {
-    u64* d_bounds = (u64*)c->xfer_meta.p;
-    u64* d_cursor = d_bounds + 2 * MK_MAX_OWNERS;
-    u64 cur[MK_MAX_OWNERS], at = 0;
-    for (int j = 0; j < MK_MAX_OWNERS; ++j) {
-      cur[j] = at;
-      if (j < n) at += counts[j];
+  if (d_rows && total > cap_rows) {
+    c->err = "rows by owner: buffer of " + std::to_string(cap_rows) + " rows is too small for " + std::to_string(total);
+    return MK_ERR_RANGE;
+  }
+  if (side) {
+    // the one key kept beside the table: an ordinary row {all-ones key, count} at the END of the buffer's rows, counted
+    // for side_owner.  (With side_owner = the last owner -- the key is the largest there is -- that is the end of its
+    // segment; mk_merge_devices gathering to one owner has only that owner.)
+    if (d_rows) {
+      u64 at = 0;
+      for (int j = 0; j < n; ++j) at += counts[j];
+      const u64 row[2] = {MK_EMPTY, c->run_side};
+      MK_HIP(hipMemcpyAsync(d_rows + at * (u64)rw, row, sizeof row, hipMemcpyHostToDevice, c->stream));
+      MK_HIP(hipStreamSynchronize(c->stream));
     }
-    MK_HIP(hipMemcpyAsync(d_cursor, cur, sizeof cur, hipMemcpyHostToDevice, c->stream));
-    const unsigned grid = grid_for(t.slots, 256 * 16, 2048);
-    if (t.kind == 1) hipLaunchKernelGGL(mk_owner_scatter_k<View64>, dim3(grid), dim3(256), 0, c->stream, View64{(const MkSlot*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
-    else if (t.kind == 2) hipLaunchKernelGGL(mk_owner_scatter_k<View128>, dim3(grid), dim3(256), 0, c->stream, View128{(const MkSlot128*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
-    else hipLaunchKernelGGL(mk_owner_scatter_k<ViewDense>, dim3(grid), dim3(256), 0, c->stream, ViewDense{(const u64*)t.p}, t.slots, (const u64*)d_bounds, n, d_cursor, d_rows, (u64)cap_rows);
-    MK_HIP(hipGetLastError());
+    counts[side_owner] += 1;
   }
-  if (side) {  // the last row of its owner's segment (the kernel filled counts - 1 rows of it)
-    u64 at = 0;
-    for (int j = 0; j <= side_owner; ++j) at += counts[j];
-    const u64 row[2] = {MK_EMPTY, c->run_side};
-    MK_HIP(hipMemcpyAsync(d_rows + (at - 1) * (u64)rw, row, sizeof row, hipMemcpyHostToDevice, c->stream));
-  }
-  MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
 }
 
@@ -260,16 +276,60 @@ static int enable_peer_pair(int a, int b) {
   return ok;
 }
 
+// f(i) for every context at once (each has host waits of its own: the GPUs work side by side); first error wins.
+// The helper threads are kept for the life of the process: a fresh thread pays ~100 us for its first HIP call, which
+// is a third of a whole merge at S2 size.
+class Helpers {
+ public:
+  template <class F>
+  int run(int n, F&& f) {
+    std::vector<int> rcs((size_t)n, MK_OK);
+    if (n > 1) {
+      std::unique_lock<std::mutex> g(mu_);
+      while ((int)threads_.size() < n - 1) threads_.emplace_back([this] { work(); });
+      job_ = [&](int i) { rcs[(size_t)i] = f(i); };
+      next_ = 1;
+      jobs_ = n;
+      pending_ = n - 1;
+      cv_.notify_all();
+    }
+    rcs[0] = f(0);
+    if (n > 1) {
+      std::unique_lock<std::mutex> g(mu_);
+      done_.wait(g, [&] { return pending_ == 0; });
+      jobs_ = 0;
+      job_ = nullptr;
+    }
+    for (int i = 0; i < n; ++i)
+      if (rcs[(size_t)i]) return rcs[(size_t)i];
+    return MK_OK;
+  }
+
+ private:
+  void work() {
+    std::unique_lock<std::mutex> g(mu_);
+    for (;;) {
+      cv_.wait(g, [&] { return next_ < jobs_; });
+      const int i = next_++;
+      auto job = job_;
+      g.unlock();
+      job(i);
+      g.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  std::vector<std::thread> threads_;  // (never joined: they sleep on cv_ until the process ends)
+  std::function<void(int)> job_;
+  int next_ = 0, jobs_ = 0, pending_ = 0;
+};
+static std::mutex g_merge_mu;  // one merge at a time uses the helpers
+static Helpers* g_helpers = nullptr;
 template <class F>
-static int on_every(int n, F&& f) {  // f(i) for every context at once (each has host waits of its own); first error wins
-  std::vector<int> rcs((size_t)n, MK_OK);
-  std::vector<std::thread> th;
-  for (int i = 1; i < n; ++i) th.emplace_back([&, i] { rcs[i] = f(i); });
-  rcs[0] = f(0);
-  for (auto& t : th) t.join();
-  for (int i = 0; i < n; ++i)
-    if (rcs[i]) return rcs[i];
-  return MK_OK;
+static int on_every(int n, F&& f) {
+  if (!g_helpers) g_helpers = new Helpers();
+  return g_helpers->run(n, f);
 }
 
 }  // namespace
@@ -342,6 +402,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
     for (int j = 0; j < i; ++j)
       if (ctxs[j] == c) { c0->err = "mk_merge_devices: the same context twice"; return MK_ERR_ARG; }
   }
+  std::lock_guard<std::mutex> merge_lock(g_merge_mu);
   const auto t_begin = Clock::now();
   const bool gather = (flags & MK_MERGE_GATHER) != 0;
   const int m = gather ? 1 : n;  // owners
@@ -374,7 +435,9 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
         if ((rc = mk_settle(ctxs[i])) != MK_OK) return fail(i, rc);
         total += table_of(ctxs[i]).rows;
       }
-      const size_t stride = std::max<size_t>(1, total / 16384);  // ~16 k keys in all, each context at the same rate
+      // ~512 keys per owner in all, each context at the same rate: owners within a few per cent of each other, and the
+      // host sorts a few thousand values only
+      const size_t stride = std::max<size_t>(1, total / (512 * (size_t)m));
       std::vector<std::vector<u64>> parts((size_t)n);
       int bad = -1;
       rc = on_every(n, [&](int i) { int r = sample_keys(ctxs[i], stride, parts[i]); if (r) bad = i; return r; });
@@ -393,6 +456,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   std::vector<std::vector<uint8_t>> ex_k((size_t)n);
   std::vector<std::vector<uint64_t>> ex_c((size_t)n);
   std::vector<u64> rows_before((size_t)n, 0);
+  const double s_bounds = secs(t_begin);
   const auto t_a = Clock::now();
   {
     int bad = -1;
@@ -443,7 +507,8 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
     rc = on_every(n, [&](int i) {
       mk_ctx* c = ctxs[i];
       int r;
-      if (!(gather && i == 0) && (r = mk_reset(c)) != MK_OK) { bad = i; return r; }
+      // (an owner's table is sized for what it will hold: its own segment and what arrives, duplicates included)
+      if (!(gather && i == 0) && (r = (i < m ? mk_reset_for(c, own[i] + recv[i] + 1) : mk_reset(c))) != MK_OK) { bad = i; return r; }
       if (i >= m) return MK_OK;
       if (hipSetDevice(c->device) != hipSuccess) { bad = i; c->err = "hipSetDevice failed"; return MK_ERR_HIP; }
       if (recv[i] && (r = mk_buf_reserve(c, c->xfer_in, (size_t)recv[i] * rw * sizeof(u64) + 64)) != MK_OK) { bad = i; return r; }
@@ -454,6 +519,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   }
 
   // ---- phase C: the segments travel (source i -> owner (i + s) mod n in round s: every pair of GPUs at once)
+  const double s_prepare = secs(t_begin) - s_bounds - S.s_bucket;
   const auto t_c = Clock::now();
   std::vector<hipEvent_t> sent((size_t)n, nullptr);
   auto drop_events = [&] { for (auto& e : sent) if (e) { (void)hipEventDestroy(e); e = nullptr; } };
@@ -553,6 +619,9 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
     S.max_owned = std::max<uint64_t>(S.max_owned, r);
   }
   S.s_total = secs(t_begin);
+  if (getenv("MK_VERBOSE"))
+    fprintf(stderr, "[mk] merge_devices: bounds %.0f us, bucket %.0f, reset+reserve %.0f, copies+import %.0f, text rows %.0f, total %.0f us\n",
+            s_bounds * 1e6, S.s_bucket * 1e6, s_prepare * 1e6, S.s_copy * 1e6, S.s_import * 1e6, S.s_total * 1e6);
   if (st) *st = S;
   return MK_OK;
 }

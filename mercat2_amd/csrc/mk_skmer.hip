@@ -29,6 +29,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
+#include <type_traits>
 
 #define SK_NKMAX 8              // windows per record (<= 62 - k)
 #ifndef SK_HIST_THREADS
@@ -458,7 +459,12 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
             const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
             ulonglong2 rec = sk_make_record(w.x, w.y, (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
             asm volatile("" : "+v"(rec.x), "+v"(rec.y));  // (built while the LDS answers)
+#ifdef SK_NT_STORE  // (timing experiment: streaming stores -- no L2 allocation for the record lines)
+            typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+            if (at < SK_NOFIT) __builtin_nontemporal_store(u64x2_t{rec.x, rec.y}, (u64x2_t*)&part[(size_t)at]);
+#else
             if (at < SK_NOFIT) part[(size_t)at] = rec;
+#endif
           }
         }
       } else {
@@ -514,6 +520,14 @@ __device__ __forceinline__ unsigned skc_step(unsigned slot, unsigned d) {
   else return slot >= SKC_SLOTS ? slot - SKC_SLOTS : slot;
 }
 
+// Which record of a load round a thread takes: batch h, record h * SKC_THREADS + ..; odd batches hand the 64-record
+// groups to the waves in reverse order, so that when a bucket's records come sorted by length (longest first) every
+// wave gets a long group and a short one
+#ifdef SKC_DYN
+#define SKC_JMAP(h) ((u64)(h) * SKC_THREADS + (((h) & 1) ? (unsigned)(SKC_THREADS - 64 - (threadIdx.x & ~63u)) + (threadIdx.x & 63u) : threadIdx.x))
+#else
+#define SKC_JMAP(h) ((u64)(h) * SKC_THREADS + threadIdx.x)
+#endif
 #define SKC_B 8          // k-mers of a record expanded and probed together
 #define SKC_WAVES (SKC_THREADS / 64)
 #ifndef SKC_PUSH
@@ -609,7 +623,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
     ke_n = kstart[bn + 1];
 #pragma unroll
     for (int h = 0; h < SKC_PRE; ++h) {
-      const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+      const u64 j = SKC_JMAP(h);
       if (j < hi_n - lo_n) pre[h] = part[lo_n + j];
     }
   }
@@ -666,7 +680,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           } else {
 #pragma unroll
             for (int h = 0; h < SKC_PRE; ++h) {
-              const u64 j = rb2 + (u64)h * SKC_THREADS + threadIdx.x;
+              const u64 j = rb2 + SKC_JMAP(h);
               recs2[h] = j < n ? src[j] : make_ulonglong2(0, 0);
             }
           }
@@ -682,17 +696,21 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             u64 x = rec.x, y = rec.y;
             // (the whole wave walks the loop together -- lanes without a record or with a short one just have
             // no live slots -- because the deferred-key stack below is the wave's: every lane takes part)
-            for (int base = 0; __any(base < nk); base += SKC_B) {
-              u64 kk[SKC_B], cur[SKC_B];
-              unsigned hh[SKC_B];
+            // One round = up to NB consecutive k-mers of every lane's record.  NB is a compile-time constant of the
+            // body; with SKC_DYN the wave picks the body that fits its LONGEST record (4, 6 or 8 slots: scalar
+            // branch, no per-slot tests), which pays when the records a wave holds are about equally long.
+            auto round = [&](auto nb_tag, int base) {
+              constexpr int NB = decltype(nb_tag)::value;
+              u64 kk[NB], cur[NB];
+              unsigned hh[NB];
               unsigned live = 0;  // bit u: slot u holds a key of this pass
               // every key's compare-and-swap is issued as soon as its slot is known, so that the hashing of the
               // later keys runs while the earlier ones are on their way through the LDS
               // canonical keys: the reverse complement ROLLS with the window -- the base that enters the key on the
-              // right enters its reverse complement, complemented, on the left -- one full reversal per 8 keys
+              // right enters its reverse complement, complemented, on the left -- one full reversal per round
               u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
 #pragma unroll
-              for (int u = 0; u < SKC_B; ++u) {
+              for (int u = 0; u < NB; ++u) {
                 const u64 fw = x >> kshift;
                 kk[u] = (CANON && rcv < fw) ? rcv : fw;
                 x = (x << 2) | (y >> 62);
@@ -713,7 +731,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               }
               unsigned fail = 0;
 #pragma unroll
-              for (int u = 0; u < SKC_B; ++u)
+              for (int u = 0; u < NB; ++u)
                 if ((live >> u) & 1u) {
                   if (cur[u] == MK_EMPTY || cur[u] == kk[u]) atomicAdd(&tcnt[skc_home(hh[u])], 1u);
                   else fail |= 1u << u;
@@ -721,9 +739,9 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
               // deferred keys -> the wave's stack (positions from ballots: no atomic), four slots at a time
               // so that the stack never holds more than SKC_QCAP; full groups of 64 are probed right away
 #pragma unroll
-              for (int half = 0; half < SKC_B; half += SKC_PUSH) {
+              for (int half = 0; half < NB; half += SKC_PUSH) {
 #pragma unroll
-                for (int u = half; u < half + SKC_PUSH; ++u) {
+                for (int u = half; u < half + SKC_PUSH && u < NB; ++u) {
                   const bool f = (fail >> u) & 1u;
                   const u64 m = __ballot(f);
                   if (m) {
@@ -734,7 +752,20 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 while (qcount >= 64) skc_drain(tkey, tcnt, myq, qcount, 64u, ovf);
               }
+            };
+#ifdef SKC_DYN
+            int wmax = nk;  // the wave's longest record (wave-uniform)
+            for (int d = 32; d > 0; d >>= 1) wmax = max(wmax, __shfl_xor(wmax, d));
+            wmax = __builtin_amdgcn_readfirstlane(wmax);
+            for (int base = 0; base < wmax;) {
+              const int left = wmax - base;
+              if (left <= 4) { round(std::integral_constant<int, 4>{}, base); base += 4; }
+              else if (left <= 6) { round(std::integral_constant<int, 6>{}, base); base += 6; }
+              else { round(std::integral_constant<int, SKC_B>{}, base); base += SKC_B; }
             }
+#else
+            for (int base = 0; __any(base < nk); base += SKC_B) round(std::integral_constant<int, SKC_B>{}, base);
+#endif
           }
           STAMP_ADD(tC, t0);
           if (*(volatile unsigned*)ovf) over = true;  // hint only; decided after the barrier below
@@ -762,7 +793,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         if (last && bn < p1) {
 #pragma unroll
           for (int h = 0; h < SKC_PRE; ++h) {
-            const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+            const u64 j = SKC_JMAP(h);
             pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
           }
         }
@@ -839,7 +870,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
       if (bn < p1) {
 #pragma unroll
         for (int h = 0; h < SKC_PRE; ++h) {
-          const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+          const u64 j = SKC_JMAP(h);
           pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
         }
       }
@@ -865,6 +896,40 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   }
   if (K32) wave_add(&info->side, side);
 }
+
+#ifdef SK_EXP_SORT
+// EXPERIMENT (timing only, not in the product build): the records of every bucket sorted by their number of windows,
+// longest first (classes = 8: every length its own class; classes = 2: five windows or more first) -- what a scatter
+// that files records by length class would hand the count kernel.  One workgroup per bucket, counting sort through LDS.
+__global__ __launch_bounds__(256) void mk_sk_expsort_k(ulonglong2* __restrict__ part, const u64* __restrict__ start,
+                                                       const u64* __restrict__ cursor, unsigned p1, int classes) {
+  __shared__ ulonglong2 buf[6144];
+  __shared__ unsigned cnt[64], base[64];
+  for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
+    const u64 lo = start[b], n = cursor[b] - start[b];
+    if (n == 0 || n > 6144) continue;
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) {
+      const ulonglong2 r = part[lo + i];
+      buf[i] = r;
+      const int nk = (int)(r.y & 63);
+      const int cls = classes == 2 ? (nk >= 5 ? 0 : 1) : (32 - nk);
+      atomicAdd(&cnt[cls], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned a = 0; for (int q = 0; q < 64; ++q) { base[q] = a; a += cnt[q]; } }
+    __syncthreads();
+    for (u64 i = threadIdx.x; i < n; i += blockDim.x) {
+      const ulonglong2 r = buf[i];
+      const int nk = (int)(r.y & 63);
+      const int cls = classes == 2 ? (nk >= 5 ? 0 : 1) : (32 - nk);
+      part[lo + atomicAdd(&base[cls], 1u)] = r;
+    }
+    __syncthreads();
+  }
+}
+#endif
 
 // ------------------------------------------------------------------------------ launcher
 
@@ -1000,6 +1065,11 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
       return MK_ERR_ARG;
   }
   mk_prof_end(c);
+#ifdef SK_EXP_SORT
+  if (const char* e = getenv("MK_EXP_SORT"))
+    hipLaunchKernelGGL(mk_sk_expsort_k, dim3(2048), dim3(256), 0, c->stream, (ulonglong2*)c->part.p, (const u64*)start, (const u64*)cursor,
+                       (unsigned)p1, atoi(e));
+#endif
   mk_prof_begin(c, MK_K_COUNT);
   {
     int ncu = 256;

@@ -147,7 +147,6 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
         cap = ctx.rows() + 1
         rows = torch.empty((cap, words + 1), dtype=torch.int64, device=dev)
         send_l = ctx.bucket_rows_device(bounds, rows.data_ptr(), cap) if packed else [0] * world
-        ctx.reset()
         meta_dev = torch.device("cpu") if staged else dev
         meta = torch.tensor([[n, int(ex_c.size)] for n in send_l], dtype=torch.int64, device=meta_dev)
         got_meta = torch.empty_like(meta)
@@ -156,6 +155,7 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
         recv_l = got_meta[:, 0].tolist()
         extras = [int(x) for x in got_meta[:, 1].tolist()]
         n_send, n_recv = int(sum(send_l)), int(sum(recv_l))
+        ctx.reset(n_recv + 1)  # (emptied and sized for this rank's share: a table that fits the caches imports faster)
         if staged:
             out_h = torch.empty((n_recv, words + 1), dtype=torch.int64)
             dist.all_to_all_single(out_h, rows[:n_send].cpu(), recv_l, send_l, group=group)

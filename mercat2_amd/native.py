@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t", "mk_write_merged_tsv_as_reference",
     "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
     "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
-    "mk_device_count",
+    "mk_device_count", "mk_reset_for",
 ]
 MK_ABI = 3  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
 MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED = 0, 1, 2
@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         "mk_destroy": (None, [vp]),
         "mk_last_error": (C.c_char_p, [vp]),
         "mk_reset": (C.c_int, [vp]),
+        "mk_reset_for": (C.c_int, [vp, C.c_uint64]),
         "mk_set_canonical": (C.c_int, [vp, C.c_int]),
         "mk_chunk_begin": (C.c_int, [vp]),
         "mk_chunk_feed": (C.c_int, [vp, u8p, C.c_size_t]),
@@ -483,8 +484,13 @@ class Counter:
         """Opt-in extension (not reference behaviour): count min(kmer, reverse complement)."""
         self._check(self._L.mk_set_canonical(self._h, 1 if on else 0))
 
-    def reset(self):
-        self._check(self._L.mk_reset(self._h))
+    def reset(self, expect_rows: int = 0):
+        """Forget the running table; with ``expect_rows`` also size it for about that many keys if that is less than
+        it has now (mk_reset_for: an owner about to take in its 1/N of a merged table)."""
+        if expect_rows:
+            self._check(self._L.mk_reset_for(self._h, int(expect_rows)))
+        else:
+            self._check(self._L.mk_reset(self._h))
 
     def count_chunk(self, data, min_count: int):
         """One reference find_kmers call: count ``data`` (raw FASTA bytes), keep >= min_count,
