@@ -308,9 +308,11 @@ uint32_t mk_crc32_of(const uint8_t* p, size_t n, uint32_t seed);
  * into ">{name}_{i} {info}" pieces re-wrapped at 80 columns, the others are written back line by line;
  * toupper != 0 upper-cases sequence lines on output.  text = the (decompressed) file; *out receives a
  * malloc'ed buffer with the cleaned text (release it with mk_free), st the figures GC content is made of.
- * MK_ERR_RANGE: a record to be split has an empty header (the reference raises IndexError).  When a
- * sequence to be split holds a blank, tab or hyphen (textwrap would treat it as a word break) nothing is
- * produced and st->unsupported_record names the record: the Python host layer then rewrites that file. */
+ * MK_ERR_RANGE: a record to be split has an empty header (the reference raises IndexError).  A sequence to be
+ * split that holds blanks, tabs or hyphens is wrapped by the standard library's word rules, as textwrap.wrap does it
+ * for the reference (restated in csrc/mk_host.cpp, checked against textwrap itself: mk_textwrap).  Header lines may
+ * hold any bytes; a byte >= 0x80 in a SEQUENCE line is MK_ERR_NON_ASCII (st->unsupported_record names the record),
+ * as in the counting calls. */
 typedef struct mk_clean_stats_t {
   uint64_t gc_count;      /* 'G' + 'C' as the reference counts them (header lines of split records included) */
   uint64_t total_length;  /* the length it divides by: GC content = 100 * gc_count / total_length            */
@@ -319,6 +321,9 @@ typedef struct mk_clean_stats_t {
 } mk_clean_stats_t;
 int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t** out, size_t* out_len, mk_clean_stats_t* st);
 void mk_free(void* p);
+/* textwrap.wrap(text, width) of CPython 3.10 for ASCII text, as mk_remove_n applies it to the pieces of a split
+ * sequence: the lines, each followed by '\n', in a malloc'ed buffer (mk_free).  A self-check for tests. */
+int mk_textwrap(const uint8_t* text, size_t n, size_t width, uint8_t** out, size_t* out_len);
 /* Deterministic synthetic reads: genome of `genome_len` iid ACGT from
  * splitmix64(genome_seed); `reads` reads of `read_len` from uniform starts, reverse-complemented
  * on a coin flip, per-base substitution with probability sub_ppm/1e6, all from

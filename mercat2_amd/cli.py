@@ -19,7 +19,7 @@ import timeit
 from pathlib import Path
 
 from . import __version__
-from .fasta import removeN_text
+from .fasta import removeN_start
 from .harness import run_sample, run_text
 from .report import merge_counters, merge_counters_T
 
@@ -55,6 +55,10 @@ def parseargs(argv=None):
     p.add_argument("-gpu", type=int, default=None, help="use exactly this one HIP device (overrides -gpus)")
     p.add_argument("-streams", type=int, default=None,
                    help="engine contexts counting chunks concurrently [2 for one-word keys, else 1]")
+    p.add_argument("-union", action="store_true",
+                   help="combined_<type>.tsv as the true union of the samples' tables (one row per k-mer in any sample). Default: "
+                        "the rows MerCat2's merge_tsv writes, whose streaming loop leaves out or misplaces k-mers that not "
+                        "all samples share (combined_<type>_T.tsv is always the union)")
     p.add_argument("-canonical", action="store_true",
                    help="EXTENSION (not MerCat2 behaviour): count min(kmer, reverse complement) for nucleotide input")
     p.add_argument("--version", "-v", action="version", version=f"mercat2_amd {__version__}")
@@ -123,6 +127,33 @@ def main(argv=None) -> int:
         kind, base = classify(f.expanduser().absolute())
         if kind:
             samples[kind][base] = f
+
+    from concurrent.futures import ThreadPoolExecutor
+    # ---- "Loading files" (bin/mercat2.py:229-298): nucleotide FASTA goes through removeN unless -skipclean.  The text
+    # rewrite is native and fast; the level-9 gzip of <base>_clean.fna.gz is not (~1.5 MB/s), so the files are written
+    # by background threads while the counting below already runs on the cleaned text in memory.
+    print("Loading files")
+    load_start = timeit.default_timer()
+    clean = not args.skipclean
+    cleaned = {}  # base -> (clean file, cleaned bytes, future of its .gz size, timings)
+    gz_writers = ThreadPoolExecutor(max(1, min(int(args.n), 16)))
+    if clean and samples["nucleotide"]:
+        keep_budget = 8 << 30  # cleaned text held in memory for the count phase; beyond it samples are counted from their file
+
+        def load(item):
+            base, f = item
+            t = {}
+            path, _gc, text, fut = removeN_start(f, out / "clean", args.toupper, gz_writers, timings=t)
+            return base, (path, text, fut, t)
+        with ThreadPoolExecutor(max(1, min(int(args.n), 8, len(samples["nucleotide"])))) as pool:
+            held = 0
+            for base, job in pool.map(load, samples["nucleotide"].items()):
+                held += len(job[1])
+                if held > keep_budget:
+                    job = (job[0], None, job[2], job[3])  # (counted from the finished .gz instead)
+                cleaned[base] = job
+    print(f"Time to load {len(samples['nucleotide']) + len(samples['protein'])} files: {round(timeit.default_timer() - load_start, 2)} seconds")
+
     for kind in ("nucleotide", "protein"):
         if not samples[kind]:
             continue
@@ -138,8 +169,6 @@ def main(argv=None) -> int:
         workers = max(1, min(int(args.n), max(8, 2 * len(devices)), len(samples[kind])))
         threads = max(2, 16 // workers)  # reader/decoder threads per sample: about 16 in all
 
-        clean = kind == "nucleotide" and not args.skipclean
-
         def one(numbered):
             idx, (base, f) = numbered
             lines = []
@@ -149,16 +178,26 @@ def main(argv=None) -> int:
             home = devices[idx % len(devices)]
             t = {}
             t0 = timeit.default_timer()
-            if clean:
-                # removeN, then count the cleaned text straight from memory; the size of <base>_clean.fna.gz on
-                # disk decides about chunking, as it does in the reference (bin/mercat2.py:101, 243)
-                clean_file, _gc, cleaned = removeN_text(f, out / "clean", args.toupper, timings=t)
-                chunked = args.s > 0 and os.stat(clean_file).st_size >= args.s * 1024 * 1024
-                run_text(base, cleaned, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, chunked,
-                         device=home, devices=devices if chunked else None, streams=args.streams, canonical=args.canonical,
-                         report=lines.append, keep=tables, timings=t)
+            tsv = tsv_dir / f"{base}_counts.tsv"
+            if kind == "nucleotide" and clean:
+                # the cleaned text is counted straight from memory; the size of <base>_clean.fna.gz on disk decides
+                # about chunking, as it does in the reference (bin/mercat2.py:101, 243) -- a file is never larger than
+                # a few bytes more than its text, so the wait for the writer is only needed from the chunk size on
+                clean_file, text, fut, t_load = cleaned[base]
+                t.update(t_load)
+                limit = args.s * 1024 * 1024
+                if text is None:
+                    fut.result()
+                    run_sample(base, clean_file, tsv, args.k, args.c, args.s, device=home,
+                               devices=[home] + [d for d in devices if d != home], streams=args.streams, canonical=args.canonical,
+                               report=lines.append, keep=tables, threads=threads if workers > 1 else 0, timings=t)
+                else:
+                    chunked = args.s > 0 and len(text) + 64 + len(text) // 1000 >= limit and fut.result() >= limit
+                    run_text(base, text, tsv, args.k, args.c, args.s, chunked, device=home, devices=devices if chunked else None,
+                             streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables, timings=t)
+                    cleaned[base] = (clean_file, None, fut, t_load)  # (the text is no longer needed)
             else:
-                run_sample(base, f, tsv_dir / f"{base}_counts.tsv", args.k, args.c, args.s, device=home,
+                run_sample(base, f, tsv, args.k, args.c, args.s, device=home,
                            devices=[home] + [d for d in devices if d != home], streams=args.streams, canonical=args.canonical,
                            report=lines.append, keep=tables, threads=threads if workers > 1 else 0, timings=t)
             if args.debug:
@@ -168,7 +207,6 @@ def main(argv=None) -> int:
         if workers == 1:
             results = map(one, enumerate(samples[kind].items()))
         else:
-            from concurrent.futures import ThreadPoolExecutor
             pool = ThreadPoolExecutor(workers)
             results = pool.map(one, enumerate(samples[kind].items()))
         for lines in results:
@@ -180,11 +218,22 @@ def main(argv=None) -> int:
         try:
             if tables:
                 stem = "combined_Nucleotide" if kind == "nucleotide" else "combined_protein"
-                merge_counters(tables, out / (stem + ".tsv"))
-                merge_counters_T(tables, out / (stem + "_T.tsv"))  # bin/mercat2.py:154-157, read by beta diversity
+                rows = merge_counters(tables, out / (stem + ".tsv"), as_reference=not args.union)
+                union_rows = merge_counters_T(tables, out / (stem + "_T.tsv"))  # bin/mercat2.py:154-157, read by beta diversity
+                if rows != union_rows:
+                    print(f"Note: {stem}.tsv has {rows} rows, the samples hold {union_rows} different k-mers: MerCat2's merge_tsv "
+                          f"leaves out or misplaces k-mers that not all samples share; {stem}_T.tsv is the full table, and "
+                          f"-union writes {stem}.tsv that way too")
         finally:
             for t in tables.values():
                 t.close()
+    # the clean files must be complete before the run ends
+    wait_start = timeit.default_timer()
+    for base, (clean_file, _text, fut, _t) in cleaned.items():
+        fut.result()
+    gz_writers.shutdown()
+    if cleaned and args.debug:
+        print(f"[debug] waited {round(timeit.default_timer() - wait_start, 2)} s more for the clean/*.fna.gz writers (gzip level 9)")
     return 0
 
 

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <utility>
+#include <string>
 #include <vector>
 #include "../../include/mercat_hip.h"
 #include "mk_cutscan.h"
@@ -254,36 +255,210 @@ extern "C" int mk_synth_reads(uint64_t genome_len, uint64_t genome_seed, uint64_
 //  * -toupper upper-cases the sequence lines on output only (a lower-case 'n' is not a cut);
 //  * GC content counts 'G' + 'C' and the length over the concatenated sequence of an unsplit record, and over
 //    EVERY emitted line of a split one, header lines included, before upper-casing (lib/mercat2_fasta.py:99-100).
-// What it does not restate: textwrap's handling of blanks and hyphens INSIDE a sequence that is being split
-// (st->unsupported_record is set and nothing is produced; the Python host layer handles such a file).
+//  * a sequence that is being split and holds blanks, tabs or hyphens goes through textwrap's word rules (tw_wrap
+//    below restates them);
+//  * bytes >= 0x80: header lines may hold any (they are copied as they stand; where the reference works on decoded
+//    text -- str.strip() of a header, header.split() and len() of a split record's header -- UTF-8 sequences of
+//    Unicode white space are blanks and a character counts once); in a SEQUENCE line they are refused
+//    (MK_ERR_NON_ASCII), as the counting engine refuses them.
 namespace {
 inline bool py_space(unsigned c) { return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31); }
+
+// Length of the UTF-8 sequence at s (n bytes left) if it encodes a character str.isspace() holds for besides the
+// ASCII ones: U+0085, U+00A0, U+1680, U+2000..U+200A, U+2028, U+2029, U+202F, U+205F, U+3000; else 0.
+inline size_t uni_space(const uint8_t* s, size_t n) {
+  if (n >= 2 && s[0] == 0xC2 && (s[1] == 0x85 || s[1] == 0xA0)) return 2;
+  if (n >= 3 && s[0] == 0xE1 && s[1] == 0x9A && s[2] == 0x80) return 3;
+  if (n >= 3 && s[0] == 0xE2 && s[1] == 0x80 && ((s[2] >= 0x80 && s[2] <= 0x8A) || s[2] == 0xA8 || s[2] == 0xA9 || s[2] == 0xAF)) return 3;
+  if (n >= 3 && s[0] == 0xE2 && s[1] == 0x81 && s[2] == 0x9F) return 3;
+  if (n >= 3 && s[0] == 0xE3 && s[1] == 0x80 && s[2] == 0x80) return 3;
+  return 0;
+}
+// the same, for a sequence that ENDS at s + n
+inline size_t uni_space_before(const uint8_t* s, size_t n) {
+  if (n >= 2 && uni_space(s + n - 2, 2) == 2) return 2;
+  if (n >= 3 && uni_space(s + n - 3, 3) == 3) return 3;
+  return 0;
+}
 
 struct LineReader {  // text-mode readline + strip over a byte buffer
   const uint8_t* p;
   size_t n, pos = 0;
+  // where the next '\n' / '\r' at or after pos is (n = none): found once and kept until pos has passed it, so that a
+  // file with one kind of line end only -- CR-only files have no '\n' at all -- is not searched to its end per line
+  size_t nl_at = 0, cr_at = 0;
+  bool nl_known = false, cr_known = false;
   LineReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
   // false at EOF; [a, b) = the stripped line
   bool next(size_t& a, size_t& b) {
     if (pos >= n) return false;
-    const uint8_t* s = p + pos;
-    const size_t left = n - pos;
-    const uint8_t* nl = (const uint8_t*)memchr(s, '\n', left);
-    size_t len = nl ? (size_t)(nl - s) : left;
-    const uint8_t* cr = (const uint8_t*)memchr(s, '\r', len);
-    size_t term = nl ? 1 : 0;
-    if (cr) {
-      len = (size_t)(cr - s);
-      term = (pos + len + 1 < n && s[len + 1] == '\n') ? 2 : 1;
+    if (!nl_known || nl_at < pos) {
+      const uint8_t* q = (const uint8_t*)memchr(p + pos, '\n', n - pos);
+      nl_at = q ? (size_t)(q - p) : n;
+      nl_known = true;
     }
+    if (!cr_known || cr_at < pos) {
+      const uint8_t* q = (const uint8_t*)memchr(p + pos, '\r', n - pos);
+      cr_at = q ? (size_t)(q - p) : n;
+      cr_known = true;
+    }
+    const size_t end = nl_at < cr_at ? nl_at : cr_at;  // first line end, or n
+    size_t term = 0;
+    if (end < n) term = (p[end] == '\r' && end + 1 < n && p[end + 1] == '\n') ? 2 : 1;
     a = pos;
-    b = pos + len;
-    pos += len + term;
-    while (a < b && py_space(p[a])) ++a;
-    while (b > a && py_space(p[b - 1])) --b;
+    b = end;
+    pos = end + term;
+    for (;;) {  // str.strip()
+      if (a < b && py_space(p[a])) { ++a; continue; }
+      const size_t u = a < b && p[a] >= 0x80 ? uni_space(p + a, b - a) : 0;
+      if (!u) break;
+      a += u;
+    }
+    for (;;) {
+      if (b > a && py_space(p[b - 1])) { --b; continue; }
+      const size_t u = b > a && p[b - 1] >= 0x80 ? uni_space_before(p + a, b - a) : 0;
+      if (!u) break;
+      b -= u;
+    }
     return true;
   }
 };
+
+// ---- textwrap.wrap(text, 80) for ASCII text (CPython 3.10 Lib/textwrap.py: TextWrapper with its defaults:
+//      expand_tabs, replace_whitespace, drop_whitespace, break_long_words, break_on_hyphens, tabsize 8) ----------
+// split_sequenceN wraps every piece of a split sequence with it (lib/mercat2_fasta.py:47).  For a piece without
+// blanks and hyphens that is "80 characters per line"; with them the standard library's word rules apply, and they
+// are restated here so that no Python copy of removeN is needed: _munge_whitespace, wordsep_re, _wrap_chunks,
+// _handle_long_word.
+inline bool tw_ws(unsigned c) { return c == ' ' || (c >= 9 && c <= 13); }                  // textwrap._whitespace
+inline bool tw_word(unsigned c) { return (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == '_'; }  // \w
+inline bool tw_letter(unsigned c) { return tw_word(c) && !(c >= '0' && c <= '9'); }        // [^\d\W]
+inline bool tw_wp(unsigned c) { return tw_word(c) || c == '!' || c == '"' || c == '\'' || c == '&' || c == '.' || c == ',' || c == '?'; }
+
+// chunks of wordsep_re.split(t): every position of t is matched by one of the pattern's three alternatives, so the
+// chunks tile the text; returned as end offsets
+static void tw_split(const std::string& t, std::vector<size_t>& ends) {
+  const size_t n = t.size();
+  auto at = [&](size_t i) -> unsigned { return i < n ? (unsigned char)t[i] : 0u; };
+  size_t i = 0;
+  while (i < n) {
+    size_t e;
+    if (tw_ws(at(i))) {  // any whitespace: ws+
+      e = i;
+      while (e < n && tw_ws(at(e))) ++e;
+    } else {
+      e = 0;
+      // em-dash between words: (?<=wp) -{2,} (?=\w)
+      if (at(i) == '-' && i > 0 && tw_wp(at(i - 1))) {
+        size_t h = i;
+        while (h < n && at(h) == '-') ++h;
+        if (h - i >= 2 && h < n && tw_word(at(h))) e = h;
+      }
+      if (!e) {
+        // word, possibly hyphenated: nws+? then the first of (hyphen with letters around | end of word | before an em-dash)
+        for (size_t p = i + 1;; ++p) {  // p = end of the lazily grown nws+?  (t[i .. p) holds no whitespace)
+          if (p < n && at(p) == '-') {
+            const bool behind = (p >= 2 && tw_letter(at(p - 1)) && tw_letter(at(p - 2))) ||
+                                (p >= 3 && tw_letter(at(p - 1)) && at(p - 2) == '-' && tw_letter(at(p - 3)));
+            const bool ahead = tw_letter(at(p + 1)) && (tw_letter(at(p + 2)) || (at(p + 2) == '-' && tw_letter(at(p + 3))));
+            if (behind && ahead) { e = p + 1; break; }
+          }
+          if (p >= n || tw_ws(at(p))) { e = p; break; }  // end of word
+          if (tw_wp(at(p - 1)) && at(p) == '-') {        // before an em-dash: (?<=wp)(?=-{2,}\w)
+            size_t h = p;
+            while (h < n && at(h) == '-') ++h;
+            if (h - p >= 2 && h < n && tw_word(at(h))) { e = p; break; }
+          }
+        }
+      }
+    }
+    ends.push_back(e);
+    i = e;
+  }
+}
+
+// the lines of textwrap.wrap(piece, width): f(const char* line, size_t len) per line
+template <class F>
+static void tw_wrap(const uint8_t* piece, size_t len, size_t width, F&& emit) {
+  // _munge_whitespace: expandtabs(8), then every whitespace character becomes a blank
+  std::string t;
+  t.reserve(len + 16);
+  size_t col = 0;
+  for (size_t i = 0; i < len; ++i) {
+    const unsigned c = piece[i];
+    if (c == '\t') {
+      const size_t pad = 8 - col % 8;
+      t.append(pad, ' ');
+      col += pad;
+    } else if (c == '\n' || c == '\r') {  // (cannot occur inside a piece; str.expandtabs restarts its column there)
+      t.push_back(' ');
+      col = 0;
+    } else {
+      t.push_back(tw_ws(c) ? ' ' : (char)c);
+      col += 1;
+    }
+  }
+  std::vector<size_t> ends;
+  tw_split(t, ends);
+  // chunks as (begin, end) in t; _wrap_chunks works on the reversed list: `next` walks forward instead
+  std::vector<std::pair<size_t, size_t>> chunks;
+  {
+    size_t b = 0;
+    for (size_t e : ends) { if (e > b) chunks.emplace_back(b, e); b = e; }
+  }
+  auto blank = [&](const std::pair<size_t, size_t>& c) {  // chunk.strip() == '' (str.strip: also \x1c..\x1f)
+    for (size_t i = c.first; i < c.second; ++i)
+      if (!py_space((unsigned char)t[i])) return false;
+    return true;
+  };
+  size_t next = 0;
+  bool any_line = false;
+  std::string line;
+  while (next < chunks.size()) {
+    line.clear();
+    size_t cur_len = 0;
+    size_t last_b = 0, last_e = 0;  // the last chunk put on the line (for the trailing-whitespace drop)
+    bool have_last = false;
+    if (blank(chunks[next]) && any_line) { ++next; if (next >= chunks.size()) break; }
+    while (next < chunks.size()) {
+      const size_t l = chunks[next].second - chunks[next].first;
+      if (cur_len + l <= width) {
+        line.append(t, chunks[next].first, l);
+        last_b = line.size() - l; last_e = line.size(); have_last = true;
+        cur_len += l;
+        ++next;
+      } else break;
+    }
+    if (next < chunks.size() && chunks[next].second - chunks[next].first > width) {  // _handle_long_word
+      const size_t space_left = width < 1 ? 1 : width - cur_len;
+      auto& c = chunks[next];
+      size_t end = space_left;
+      if (c.second - c.first > space_left) {  // break after the last hyphen that has a non-hyphen before it
+        size_t hy = std::string::npos;
+        for (size_t q = space_left; q-- > 0;)
+          if (t[c.first + q] == '-') { hy = q; break; }
+        if (hy != std::string::npos && hy > 0) {
+          bool other = false;
+          for (size_t q = 0; q < hy; ++q)
+            if (t[c.first + q] != '-') { other = true; break; }
+          if (other) end = hy + 1;
+        }
+      }
+      if (end > c.second - c.first) end = c.second - c.first;
+      line.append(t, c.first, end);
+      last_b = line.size() - end; last_e = line.size(); have_last = true;
+      c.first += end;  // (the rest of the chunk stays at the head of the list; an emptied chunk has length 0 and is taken next)
+    }
+    if (have_last) {  // drop a trailing all-whitespace chunk
+      bool ws = true;
+      for (size_t q = last_b; q < last_e; ++q)
+        if (!py_space((unsigned char)line[q])) { ws = false; break; }
+      if (ws) line.resize(last_b);
+    }
+    if (!line.empty()) { emit(line.data(), line.size()); any_line = true; }
+    else if (!have_last && next < chunks.size() && chunks[next].second == chunks[next].first) ++next;  // (an emptied chunk)
+  }
+}
 }  // namespace
 
 extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t** out, size_t* out_len, mk_clean_stats_t* st) {
@@ -292,11 +467,6 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
   *out_len = 0;
   memset(st, 0, sizeof *st);
   st->unsupported_record = -1;
-  for (size_t i = 0; i < n; ++i)
-    if (text[i] >= 0x80) {  // the reference works on decoded characters (lengths, wrapping): left to the Python layer
-      st->unsupported_record = 0;
-      return MK_OK;
-    }
   std::vector<uint8_t> o;
   o.reserve(n + n / 64 + 4096);
   std::vector<uint8_t> seq;
@@ -314,11 +484,15 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
         if (o[i] >= 'a' && o[i] <= 'z') o[i] = (uint8_t)(o[i] - 32);
     o.push_back('\n');
   };
+  // G + C and the length in CHARACTERS (a header line of a split record may hold multi-byte characters)
   auto count_gc = [&](const uint8_t* s, size_t len) {
-    uint64_t g = 0;
-    for (size_t i = 0; i < len; ++i) g += (s[i] == 'G') | (s[i] == 'C');
+    uint64_t g = 0, cont = 0;
+    for (size_t i = 0; i < len; ++i) {
+      g += (s[i] == 'G') | (s[i] == 'C');
+      cont += (s[i] & 0xC0) == 0x80;  // UTF-8 continuation bytes
+    }
     st->gc_count += g;
-    st->total_length += len;
+    st->total_length += len - cont;
   };
   while (have) {
     if (!(a < b && text[a] == '>')) {  // not a header: skipped (only happens in front of the first one)
@@ -333,6 +507,11 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
     while ((have = rd.next(a, b))) {
       if (a < b && text[a] == '>') break;
       lines.emplace_back(a, b);
+      for (size_t i = a; i < b; ++i)
+        if (text[i] >= 0x80) {  // non-ASCII sequence text: refused here as the counting engine refuses it
+          st->unsupported_record = (int64_t)st->records - 1;
+          return MK_ERR_NON_ASCII;
+        }
       if (!has_n && a < b && memchr(text + a, 'N', b - a)) has_n = true;
     }
     if (!has_n) {
@@ -347,17 +526,17 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
     }
     // split at runs of N
     for (auto& ln : lines) seq.insert(seq.end(), text + ln.first, text + ln.second);
-    for (uint8_t ch : seq)
-      if (ch == ' ' || ch == '\t' || ch == 0x0b || ch == 0x0c || ch == '-' || (ch >= 0x1c && ch <= 0x1f)) {
-        st->unsupported_record = (int64_t)st->records - 1;
-        return MK_OK;
-      }
-    // header words
+    // header words: header.split() (white space of any kind, Unicode's included)
     std::vector<std::pair<size_t, size_t>> words;
     for (size_t i = name_a; i < name_b;) {
-      while (i < name_b && py_space(text[i])) ++i;
+      for (;;) {
+        if (i < name_b && py_space(text[i])) { ++i; continue; }
+        const size_t u = i < name_b && text[i] >= 0x80 ? uni_space(text + i, name_b - i) : 0;
+        if (!u) break;
+        i += u;
+      }
       size_t j = i;
-      while (j < name_b && !py_space(text[j])) ++j;
+      while (j < name_b && !py_space(text[j]) && !(text[j] >= 0x80 && uni_space(text + j, name_b - j))) ++j;
       if (j > i) words.emplace_back(i, j);
       i = j;
     }
@@ -367,7 +546,11 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
     const size_t L = seq.size();
     for (;;) {  // pieces = seq.split at N+ (leading / trailing runs give empty pieces)
       size_t j = i;
-      while (j < L && seq[j] != 'N') ++j;
+      bool words_matter = false;  // blanks or hyphens: textwrap's word rules instead of plain 80-column cuts
+      for (; j < L && seq[j] != 'N'; ++j) {
+        const uint8_t ch = seq[j];
+        words_matter |= ch == '-' || py_space(ch);
+      }
       ++piece;
       const size_t h0 = o.size();
       o.push_back('>');
@@ -383,10 +566,17 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
       }
       count_gc(o.data() + h0, o.size() - h0);  // (the reference counts the header line of a split record too)
       o.push_back('\n');
-      for (size_t q = i; q < j; q += 80) {
-        const size_t len = j - q < 80 ? j - q : 80;
-        count_gc(seq.data() + q, len);
-        put_seq(seq.data() + q, len, seq[q] != '>');
+      if (!words_matter) {
+        for (size_t q = i; q < j; q += 80) {
+          const size_t len = j - q < 80 ? j - q : 80;
+          count_gc(seq.data() + q, len);
+          put_seq(seq.data() + q, len, seq[q] != '>');
+        }
+      } else {
+        tw_wrap(seq.data() + i, j - i, 80, [&](const char* line, size_t len) {
+          count_gc((const uint8_t*)line, len);
+          put_seq((const uint8_t*)line, len, line[0] != '>');
+        });
       }
       st->pieces += 1;
       if (j >= L) break;
@@ -395,6 +585,19 @@ extern "C" int mk_remove_n(const uint8_t* text, size_t n, int toupper, uint8_t**
       i = j;
     }
   }
+  uint8_t* mem = (uint8_t*)malloc(o.size() ? o.size() : 1);
+  if (!mem) return MK_ERR_NOMEM;
+  memcpy(mem, o.data(), o.size());
+  *out = mem;
+  *out_len = o.size();
+  return MK_OK;
+}
+
+// textwrap.wrap(text, width) as restated above, for tests against the standard library: lines joined by '\n'.
+extern "C" int mk_textwrap(const uint8_t* text, size_t n, size_t width, uint8_t** out, size_t* out_len) {
+  if (!out || !out_len || (n && !text) || width < 1) return MK_ERR_ARG;
+  std::string o;
+  tw_wrap(text, n, width, [&](const char* line, size_t len) { o.append(line, len); o.push_back('\n'); });
   uint8_t* mem = (uint8_t*)malloc(o.size() ? o.size() : 1);
   if (!mem) return MK_ERR_NOMEM;
   memcpy(mem, o.data(), o.size());

@@ -11,8 +11,6 @@ from __future__ import annotations
 
 import gzip
 import os
-import re
-import textwrap
 from pathlib import Path
 from typing import Optional, Dict, Tuple
 
@@ -20,67 +18,46 @@ from . import native
 from .kmers import read_fasta_bytes
 
 
-def split_sequenceN(header: str, sequence: str):
-    """lib/mercat2_fasta.py:21-49 (same arguments and result): used for the records ``mk_remove_n`` leaves to
-    this layer -- a sequence to be split that holds blanks or hyphens, which textwrap treats as word breaks."""
-    n_lengths = [len(m.group(1)) for m in re.finditer(r"(N+)", sequence)]
-    pieces = re.sub(r"(N+)", "\n", sequence).split("\n")
-    words = header.split()
-    basename, info = words[0], " ".join(words[1:])
-    seqs = []
-    for i, seq in enumerate(pieces, 1):
-        seqs.append(f">{basename}_{i} {info}")
-        seqs += textwrap.wrap(seq, 80)
-    return seqs, n_lengths
-
-
-def _clean_text_py(text: str, toupper: bool) -> Tuple[str, int, int]:
-    """The whole rewrite in Python, for the rare file the native code declines (see split_sequenceN)."""
-    out = []
-    gc = total = 0
-    lines = text.splitlines(keepends=True) if False else None  # (text-mode readline semantics: only \n, \r, \r\n end a line)
-    lines = re.split(r"\r\n|\r|\n", text)
-    if lines and lines[-1] == "":
-        lines.pop()
-    i = 0
-    while i < len(lines):
-        line = lines[i].strip()
-        if not line.startswith(">"):
-            i += 1
-            continue
-        name = line[1:]
-        i += 1
-        seq_line = []
-        while i < len(lines):
-            cur = lines[i].strip()
-            if cur.startswith(">"):
-                break
-            seq_line.append(cur)
-            i += 1
-        sequence = "".join(seq_line)
-        if "N" in sequence:
-            pieces, _ = split_sequenceN(name, sequence)
-            for s in pieces:
-                out.append(s if s.startswith(">") or not toupper else s.upper())
-                gc += s.count("G") + s.count("C")
-                total += len(s)
-        else:
-            out.append(">" + name)
-            out += [s.upper() for s in seq_line] if toupper else seq_line
-            gc += sequence.count("G") + sequence.count("C")
-            total += len(sequence)
-    return "".join(s + "\n" for s in out), gc, total
-
-
 def clean_text(raw, toupper: bool = False) -> Tuple[bytes, Dict[str, float]]:
     """removeN on FASTA bytes already in memory: (cleaned text, {'GC Content': percent}).  Raises
     ZeroDivisionError for input without sequence and IndexError for a record to be split whose header is
-    empty, as the reference does."""
+    empty, as the reference does; a byte >= 0x80 in a sequence line raises native.NonAsciiInput (the counting
+    engine refuses such text too)."""
     cleaned, st = native.remove_n(raw, toupper)
-    if st["unsupported_record"] >= 0:
-        text, gc, total = _clean_text_py(bytes(raw).decode("utf-8"), toupper)
-        cleaned, st = text.encode("utf-8"), dict(st, gc_count=gc, total_length=total)
     return cleaned, {"GC Content": 100.0 * st["gc_count"] / st["total_length"]}
+
+
+def _write_clean_gz(out_fasta: Path, cleaned, timings: Optional[dict] = None) -> int:
+    """<base>_clean.fna.gz exactly as the reference's text-mode gzip writer leaves it (level 9, one flush on close):
+    its SIZE decides whether the sample is chunked (bin/mercat2.py:101).  Returns that size."""
+    import timeit
+    t0 = timeit.default_timer()
+    with gzip.open(out_fasta, "wb") as writer:
+        writer.write(cleaned)
+        writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
+    if timings is not None:
+        timings["gzip_s"] = timeit.default_timer() - t0
+    return os.stat(out_fasta).st_size
+
+
+def removeN_start(fasta: Path, outpath: Path, toupper: bool, writers, timings: Optional[dict] = None):
+    """removeN with the level-9 DEFLATE off the critical path: the file is read and rewritten (native code, memory
+    speed) here; writing ``<base>_clean.fna.gz`` -- ~1.5 MB/s of zlib on DNA, a hundred times slower than everything
+    else on the way to the table -- is handed to the executor ``writers`` (zlib releases the GIL).  Returns
+    ``(path, stats, cleaned bytes, future)``; ``future.result()`` is the size of the finished file.  The counting path
+    takes the bytes from memory and needs that size only when the cleaned text itself reaches the chunk size."""
+    import timeit
+    os.makedirs(outpath, exist_ok=True)
+    basename = Path(fasta).stem.split(".")[0]
+    out_fasta = Path(outpath, f"{basename}_clean.fna.gz")
+    t0 = timeit.default_timer()
+    raw = read_fasta_bytes(fasta)
+    t1 = timeit.default_timer()
+    cleaned, stats = clean_text(raw, toupper)
+    if timings is not None:
+        timings.update(read_s=t1 - t0, clean_s=timeit.default_timer() - t1)
+    future = writers.submit(_write_clean_gz, out_fasta, cleaned, timings)
+    return out_fasta.absolute(), stats, cleaned, future
 
 
 def removeN_text(fasta: Path, outpath: Path, toupper: bool, timings: Optional[dict] = None):
@@ -95,12 +72,9 @@ def removeN_text(fasta: Path, outpath: Path, toupper: bool, timings: Optional[di
     raw = read_fasta_bytes(fasta)
     t1 = timeit.default_timer()
     cleaned, stats = clean_text(raw, toupper)
-    t2 = timeit.default_timer()
-    with gzip.open(out_fasta, "wb") as writer:
-        writer.write(cleaned)
-        writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
     if timings is not None:
-        timings.update(read_s=t1 - t0, clean_s=t2 - t1, gzip_s=timeit.default_timer() - t2)
+        timings.update(read_s=t1 - t0, clean_s=timeit.default_timer() - t1)
+    _write_clean_gz(out_fasta, cleaned, timings)
     return out_fasta.absolute(), stats, cleaned
 
 

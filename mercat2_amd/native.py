@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t", "mk_write_merged_tsv_as_reference",
     "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
     "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
-    "mk_device_count", "mk_reset_for",
+    "mk_device_count", "mk_reset_for", "mk_textwrap",
 ]
 MK_ABI = 3  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
 MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED = 0, 1, 2
@@ -148,6 +148,7 @@ def lib() -> C.CDLL:
         "mk_filter_min": (C.c_int, [vp, C.c_uint64]),
         "mk_remove_n": (C.c_int, [u8p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), szp, C.POINTER(CleanStats)]),
         "mk_free": (None, [C.c_void_p]),
+        "mk_textwrap": (C.c_int, [u8p, C.c_size_t, C.c_size_t, C.POINTER(C.c_void_p), szp]),
         "mk_alpha_stats": (C.c_int, [vp, C.POINTER(AlphaStats)]),
         "mk_gunzip_parallel": (C.c_int, [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_size_t, szp, C.POINTER(C.c_int)]),
         "mk_crc32_of": (C.c_uint32, [u8p, C.c_size_t, C.c_uint32]),
@@ -221,14 +222,16 @@ def chunk_cuts(text, chunksize: int) -> np.ndarray:
 
 
 def remove_n(text, toupper: bool = False) -> Tuple[bytes, dict]:
-    """mk_remove_n: (cleaned FASTA text, mk_clean_stats_t fields).  When ``unsupported_record`` >= 0 the text is
-    empty and the caller rewrites the file itself (mercat2_amd.fasta)."""
+    """mk_remove_n: (cleaned FASTA text, mk_clean_stats_t fields).  IndexError for a record to be split whose header is
+    empty (as the reference raises it), NonAsciiInput for a byte >= 0x80 in a sequence line."""
     L = lib()
     addr, n, keep = _buf_ptr(text)
     out, out_len, st = C.c_void_p(), C.c_size_t(0), CleanStats()
     rc = L.mk_remove_n(addr, n, 1 if toupper else 0, C.byref(out), C.byref(out_len), C.byref(st))
     if rc == -7:
         raise IndexError("list index out of range")  # header.split()[0] of an empty header (lib/mercat2_fasta.py:40-41)
+    if rc == -5:
+        raise NonAsciiInput(rc, "record %d holds sequence byte(s) >= 0x80 (non-ASCII sequence text is not supported)" % st.unsupported_record)
     if rc:
         raise MercatHipError(rc, "mk_remove_n")
     try:
@@ -237,6 +240,22 @@ def remove_n(text, toupper: bool = False) -> Tuple[bytes, dict]:
         if out.value:
             L.mk_free(out)
     return data, {n_: int(getattr(st, n_)) for n_, _ in st._fields_}
+
+
+def textwrap_lines(text, width: int = 80) -> list:
+    """mk_textwrap: the lines the library's restatement of textwrap.wrap gives (bytes each)."""
+    L = lib()
+    addr, n, keep = _buf_ptr(text)
+    out, out_len = C.c_void_p(), C.c_size_t(0)
+    rc = L.mk_textwrap(addr, n, int(width), C.byref(out), C.byref(out_len))
+    if rc:
+        raise MercatHipError(rc, "mk_textwrap")
+    try:
+        data = C.string_at(out, out_len.value) if out.value else b""
+    finally:
+        if out.value:
+            L.mk_free(out)
+    return data.split(b"\n")[:-1] if data else []
 
 
 def default_streams(k: int, alphabet: int) -> int:

@@ -10,6 +10,7 @@ import pytest
 
 from conftest import GOLDEN, read_input
 from mercat2_amd import fasta, native
+from oracle import clean_ref
 
 CASES = json.loads((GOLDEN / "clean_cases.json").read_text())
 
@@ -38,11 +39,69 @@ def test_removeN_file_like_the_reference(case, tmp_path):
     assert stats == {"GC Content": c["gc"]}
 
 
-def test_native_path_is_the_one_used():
-    """The native rewrite handles every golden input but the one with word breaks inside split sequences."""
+def test_native_path_handles_every_golden_input():
+    """No input is handed to a second implementation: the native rewrite does all of them, the one with word breaks
+    inside split sequences (edge_clean_odd.fa: blanks, tabs, hyphens -- textwrap's word rules) included."""
     for case, c in CASES.items():
-        _, st = native.remove_n(read_input(c["input"]), c["toupper"])
-        assert (st["unsupported_record"] >= 0) == (c["input"] == "edge_clean_odd.fa"), case
+        text, st = native.remove_n(read_input(c["input"]), c["toupper"])
+        assert st["unsupported_record"] == -1, case
+        assert hashlib.sha256(text).hexdigest() == c["sha256"], case
+    assert not hasattr(fasta, "_clean_text_py") and not hasattr(fasta, "split_sequenceN")
+
+
+@pytest.mark.parametrize("case", sorted(CASES), ids=sorted(CASES))
+def test_oracle_restatement_is_pinned_to_the_reference(case):
+    c = CASES[case]
+    text, gc, total = clean_ref.clean_text(read_input(c["input"]).decode("utf-8"), c["toupper"])
+    assert hashlib.sha256(text.encode()).hexdigest() == c["sha256"]
+    assert 100.0 * gc / total == c["gc"]
+
+
+def test_textwrap_restatement_equals_the_standard_library():
+    """mk_textwrap (what mk_remove_n applies to the pieces of a split sequence) against textwrap.wrap itself on random
+    ASCII text full of what textwrap cares about: blanks, tabs, other white space, hyphens and dashes between letters,
+    digits and punctuation, words longer than a line."""
+    import random
+    import textwrap
+    rng = random.Random(4)
+    alphabets = ["ACGT -", "ACGTacgt \t-", "AC-G--T---x1 .,!?\"'&_", "ab-cd- e--f g\x0b\x0c\x1c\x1f\t", "A-", "-", " ", "ACGT"]
+    for case in range(3000):
+        ab = rng.choice(alphabets)
+        n = rng.choice([0, 1, 2, 5, 30, 79, 80, 81, 82, 160, 161, 400])
+        text = "".join(rng.choice(ab) for _ in range(n))
+        if rng.random() < 0.3:  # long runs without a break
+            at = rng.randrange(0, len(text) + 1)
+            text = text[:at] + "".join(rng.choice("ACGT-") for _ in range(rng.randrange(60, 200))) + text[at:]
+        for width in (80, 7, 1):
+            want = [ln.encode() for ln in textwrap.wrap(text, width)]
+            got = native.textwrap_lines(text.encode(), width)
+            assert got == want, (case, width, text)
+
+
+def test_non_ascii_bytes():
+    """Header lines may hold any bytes (where the reference works on characters -- strip, split, len -- UTF-8 is
+    understood); in a sequence line a byte >= 0x80 is refused, as the counting engine refuses it."""
+    head = ">s\u00e9q \u00a0 d\u00e9sc\u2003x\u00a0"
+    text = (head + "\nACGTNNACGT\nGG\n>plain h\u00e9\nACGT\n").encode("utf-8")
+    want, gc, total = clean_ref.clean_text(text.decode("utf-8"), False)
+    got, st = native.remove_n(text, False)
+    assert got == want.encode("utf-8")
+    assert (st["gc_count"], st["total_length"]) == (gc, total)
+    with pytest.raises(native.NonAsciiInput):
+        native.remove_n(">a\nACG\u00e9T\n".encode("utf-8"), False)
+    # a header in another encoding is copied as it stands (the reference would fail to decode the file)
+    latin = b">caf\xe9 x\nACGT\n"
+    assert native.remove_n(latin, False)[0] == latin
+
+
+def test_cr_only_files_take_linear_time():
+    import time
+    rec = b">r\r" + b"ACGT" * 20 + b"\r"
+    data = rec * 200_000  # 17 MB, no '\\n' anywhere
+    t0 = time.perf_counter()
+    out, st = native.remove_n(data, False)
+    assert time.perf_counter() - t0 < 5.0
+    assert st["records"] == 200_000 and out.count(b"\n") == 400_000 and b"\r" not in out
 
 
 def test_reference_errors_are_kept():
@@ -64,15 +123,14 @@ def test_committed_clean_file_is_reproduced():
         assert (len(got), hashlib.sha256(got).hexdigest()) == (w["bytes"], w["sha256"]), name
 
 
-def test_native_rewrite_equals_the_python_restatement_on_random_text():
-    """Differential run: mk_remove_n against mercat2_amd.fasta._clean_text_py (itself pinned to the reference's function
-    by the edge_clean_odd golden, the one input the native code declines) on random FASTA-like text: N runs anywhere,
+def test_native_rewrite_equals_the_oracle_restatement_on_random_text():
+    """Differential run: mk_remove_n against the oracle's restatement (oracle/clean_ref.py, pinned to the reference's
+    function by the goldens above) on random FASTA-like text: N runs anywhere, blanks and hyphens inside sequences,
     \\n / \\r\\n / lone \\r line ends, blank and blank-padded lines, headers with several words, text before the first
     header, empty records, a missing final newline."""
     import random
     rng = random.Random(20261004)
     alphabet = "ACGTacgtNNNnRY*"
-    declined = 0
     for case in range(400):
         parts = []
         if rng.random() < 0.3:
@@ -86,7 +144,7 @@ def test_native_rewrite_equals_the_python_restatement_on_random_text():
             lines = [head]
             for _ in range(rng.randrange(0, 5)):
                 n = rng.choice([0, 1, 7, 60, 80, 81, 200])
-                body = "".join(rng.choice(alphabet) for _ in range(n))
+                body = "".join(rng.choice(alphabet + (" -\t>" if case % 4 == 0 else "")) for _ in range(n))
                 if rng.random() < 0.2:
                     body = "N" * rng.randrange(1, 90) + body
                 if rng.random() < 0.2:
@@ -97,18 +155,12 @@ def test_native_rewrite_equals_the_python_restatement_on_random_text():
         text = "".join(parts)
         for up in (False, True):
             try:
-                want, gc, total = fasta._clean_text_py(text, up)
+                want, gc, total = clean_ref.clean_text(text, up)
             except IndexError:
                 with pytest.raises(IndexError):
                     native.remove_n(text.encode(), up)
                 continue
             got, st = native.remove_n(text.encode(), up)
-            if st["unsupported_record"] >= 0:
-                # (a record without a final line end glues the next header onto its last line: blanks inside a sequence
-                # that is split -- the case the native code hands to this layer)
-                declined += 1
-                assert fasta.clean_text(text.encode(), up)[0] == want.encode()
-                continue
+            assert st["unsupported_record"] == -1
             assert got == want.encode(), (case, up, text)
             assert (st["gc_count"], st["total_length"]) == (gc, total), (case, up, text)
-    assert declined < 200

@@ -85,11 +85,10 @@ def test_merge_devices_equals_the_oracle(k, c, alphabet, n, flags):
 
 
 def test_balanced_bounds_even_out_a_skewed_table():
-    """Keys crowded into a narrow range (every read starts with the same 40 bases): equal key ranges give nearly
-    everything to one owner, sampled splitters share the rows out."""
+    """Keys crowded into the low half of the key space (sequences over A and C only: every key starts with the bits
+    00 or 01): equal key ranges leave two of four owners empty, sampled splitters share the rows out."""
     rng = np.random.default_rng(5)
-    prefix = "ACGTTGCA" * 5
-    recs = [">r%d\n%s%s\n" % (i, prefix, "".join("ACGT"[x] for x in rng.integers(0, 4, 60))) for i in range(20000)]
+    recs = [">r%d\n%s\n" % (i, "".join("AC"[x] for x in rng.integers(0, 2, 100))) for i in range(20000)]
     data = "".join(recs).encode()
     k, n = 21, 4
     want = cpu_ref.count_text(data, k, 1)
@@ -107,8 +106,8 @@ def test_balanced_bounds_even_out_a_skewed_table():
         finally:
             for x in ctxs:
                 x.close()
-    assert out["balanced"] < 0.40, out  # four owners: 0.25 is perfect
-    assert out["balanced"] < out["equal"], out
+    assert out["equal"] > 0.45, out     # two owners hold everything
+    assert out["balanced"] < 0.32, out  # four owners: 0.25 is perfect
 
 
 @pytest.mark.parametrize("k", [31, 32, 63, 3])
