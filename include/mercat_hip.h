@@ -34,6 +34,9 @@ extern "C" {
                                  may hold any bytes: they never enter a k-mer */
 #define MK_ERR_IO (-6)        /* file could not be written */
 #define MK_ERR_RANGE (-7)     /* caller buffer too small / value out of range */
+#define MK_ERR_UNSUPPORTED (-8) /* clean mode (mk_set_clean): the chunk holds text whose rewrite by removeN the GPU does not
+                                 reproduce (a blank inside a sequence line, a '>' that does not start a header line, a
+                                 0x7F byte); nothing of the chunk was counted -- count the text mk_remove_n produces instead */
 
 /* Alphabets select the packed fast path; they never restrict the input.  Windows holding a
  * symbol outside the alphabet are still counted, exactly, by the by-reference kernel
@@ -95,6 +98,32 @@ int mk_reset_for(mk_ctx* ctx, uint64_t expect_rows);
  * first and last 32 bases -- the set the two strands share.  k > 64 and the raw alphabet count text, which has no
  * complement: MK_ERR_ARG. */
 int mk_set_canonical(mk_ctx* ctx, int on);
+
+/* removeN's effect on the count, on the GPU (lib/mercat2_fasta.py:53-119; MerCat2 runs it on every nucleotide FASTA
+ * before counting, bin/mercat2.py:239-244): with on != 0 the chunks fed from now on are RAW FASTA and are counted as
+ * if removeN had rewritten them first -- every run of upper-case 'N' cuts its record (no window spans or holds it),
+ * text in front of the first header line is not counted, and with toupper != 0 lower-case letters count as their
+ * upper-case forms (a lower-case 'n' then is an 'N' that IS counted, as in the reference, which splits before it
+ * upper-cases).  The N scan shares the parser's and packer's pass over the text; the table does not wait for the
+ * rewritten file.  Nucleotide alphabet, one chunk per file (a sample the reference would chunk is cut on the CLEANED
+ * text: count mk_remove_n's output for those).  A chunk the mode cannot reproduce is refused with MK_ERR_UNSUPPORTED
+ * and nothing of it is counted. */
+int mk_set_clean(mk_ctx* ctx, int on, int toupper);
+typedef struct mk_clean_gpu_t {
+  uint64_t raw_bytes;    /* bytes of the chunks counted in clean mode since mk_reset                              */
+  uint64_t symbols;      /* sequence characters kept (N runs excluded): the total_length removeN divides by,
+                            without the header lines of split records                                            */
+  uint64_t gc_count;     /* 'G' + 'C' among them (after -toupper if it is on)                                     */
+  uint64_t n_bytes;      /* upper-case 'N' bytes removed                                                         */
+  uint64_t n_runs;       /* runs of N = cuts = pieces added                                                      */
+  uint64_t header_lines; /* records                                                                             */
+  uint64_t last_runs;    /* runs of the last chunk (mk_clean_runs lists them)                                    */
+} mk_clean_gpu_t;
+int mk_clean_stats(mk_ctx* ctx, mk_clean_gpu_t* out);
+/* The N runs of the last chunk as [starts[i], ends[i]) in the parsed stream (kept characters in order, one separator
+ * per header line: the stream the k-mer windows slide over), ascending; *n = how many (cap values fit; at most 65536
+ * are kept per chunk).  What split_sequenceN cuts at (lib/mercat2_fasta.py:35-38). */
+int mk_clean_runs(mk_ctx* ctx, uint64_t* starts, uint64_t* ends, size_t cap, size_t* n);
 
 /* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */
 int mk_chunk_begin(mk_ctx* ctx);

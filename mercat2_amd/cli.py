@@ -19,8 +19,9 @@ import timeit
 from pathlib import Path
 
 from . import __version__
-from .fasta import removeN_start
-from .harness import run_sample, run_text
+from .fasta import removeN_background, removeN_text
+from .kmers import read_fasta_bytes
+from .harness import run_raw_clean, run_sample, run_text
 from .report import merge_counters, merge_counters_T
 
 FILE_EXT_FASTQ = [".fq", ".fastq", ".fq.gz", ".fastq.gz"]
@@ -135,22 +136,28 @@ def main(argv=None) -> int:
     print("Loading files")
     load_start = timeit.default_timer()
     clean = not args.skipclean
-    cleaned = {}  # base -> (clean file, cleaned bytes, future of its .gz size, timings)
+    cleaned = {}  # base -> [clean file, raw bytes (until counted), future of (.gz size, stats), holder of the cleaned text, timings]
     gz_writers = ThreadPoolExecutor(max(1, min(int(args.n), 16)))
     if clean and samples["nucleotide"]:
-        keep_budget = 8 << 30  # cleaned text held in memory for the count phase; beyond it samples are counted from their file
+        import threading
+        budget = [8 << 30]  # bytes of input held in memory between loading and counting; samples beyond it are read when counted
+        budget_lock = threading.Lock()
 
         def load(item):
             base, f = item
             t = {}
-            path, _gc, text, fut = removeN_start(f, out / "clean", args.toupper, gz_writers, timings=t)
-            return base, (path, text, fut, t)
+            with budget_lock:
+                room = budget[0] > 0
+                budget[0] -= os.stat(f).st_size * (4 if str(f).endswith(".gz") else 1)
+            if not room:
+                return base, None
+            t0 = timeit.default_timer()
+            raw = read_fasta_bytes(f)
+            t["read_s"] = timeit.default_timer() - t0
+            path, fut, holder = removeN_background(f, raw, out / "clean", args.toupper, gz_writers, timings=t)
+            return base, [path, raw, fut, holder, t]
         with ThreadPoolExecutor(max(1, min(int(args.n), 8, len(samples["nucleotide"])))) as pool:
-            held = 0
             for base, job in pool.map(load, samples["nucleotide"].items()):
-                held += len(job[1])
-                if held > keep_budget:
-                    job = (job[0], None, job[2], job[3])  # (counted from the finished .gz instead)
                 cleaned[base] = job
     print(f"Time to load {len(samples['nucleotide']) + len(samples['protein'])} files: {round(timeit.default_timer() - load_start, 2)} seconds")
 
@@ -180,22 +187,34 @@ def main(argv=None) -> int:
             t0 = timeit.default_timer()
             tsv = tsv_dir / f"{base}_counts.tsv"
             if kind == "nucleotide" and clean:
-                # the cleaned text is counted straight from memory; the size of <base>_clean.fna.gz on disk decides
-                # about chunking, as it does in the reference (bin/mercat2.py:101, 243) -- a file is never larger than
-                # a few bytes more than its text, so the wait for the writer is only needed from the chunk size on
-                clean_file, text, fut, t_load = cleaned[base]
-                t.update(t_load)
                 limit = args.s * 1024 * 1024
-                if text is None:
-                    fut.result()
-                    run_sample(base, clean_file, tsv, args.k, args.c, args.s, device=home,
-                               devices=[home] + [d for d in devices if d != home], streams=args.streams, canonical=args.canonical,
-                               report=lines.append, keep=tables, threads=threads if workers > 1 else 0, timings=t)
-                else:
-                    chunked = args.s > 0 and len(text) + 64 + len(text) // 1000 >= limit and fut.result() >= limit
+                if cleaned[base] is None:  # (not loaded up front: the rewrite, its file, then the count, one after the other)
+                    clean_file, _gc, text = removeN_text(f, out / "clean", args.toupper, timings=t)
+                    chunked = args.s > 0 and os.stat(clean_file).st_size >= limit
                     run_text(base, text, tsv, args.k, args.c, args.s, chunked, device=home, devices=devices if chunked else None,
                              streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables, timings=t)
-                    cleaned[base] = (clean_file, None, fut, t_load)  # (the text is no longer needed)
+                    del text
+                    t_load = {}
+                else:
+                    clean_file, raw, fut, holder, t_load = cleaned[base]
+                    # the table straight from the raw text, counted as removeN leaves it (N runs cut records: the GPU finds
+                    # them in the parser's pass), while the rewrite and the level-9 gzip of the clean file run in the background
+                    done = run_raw_clean(base, raw, tsv, args.k, args.c, args.toupper, limit, device=home, canonical=args.canonical,
+                                         report=lines.append, keep=tables, timings=t)
+                    cleaned[base][1] = raw = None
+                    if done is not None:
+                        holder["drop"]()
+                    else:
+                        # the sample may be chunked (the reference cuts the CLEANED file, and its size on disk decides,
+                        # bin/mercat2.py:101, 243), or holds text whose rewrite the GPU does not reproduce: count the text
+                        # the host rewrite produced
+                        gz_size, _stats = fut.result()
+                        text = holder.pop("text")
+                        chunked = args.s > 0 and gz_size >= limit
+                        run_text(base, text, tsv, args.k, args.c, args.s, chunked, device=home, devices=devices if chunked else None,
+                                 streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables, timings=t)
+                        del text
+                t.update(t_load)
             else:
                 run_sample(base, f, tsv, args.k, args.c, args.s, device=home,
                            devices=[home] + [d for d in devices if d != home], streams=args.streams, canonical=args.canonical,
@@ -229,8 +248,9 @@ def main(argv=None) -> int:
                 t.close()
     # the clean files must be complete before the run ends
     wait_start = timeit.default_timer()
-    for base, (clean_file, _text, fut, _t) in cleaned.items():
-        fut.result()
+    for base, job in cleaned.items():
+        if job is not None:
+            job[2].result()  # (an error of the rewrite -- e.g. a record to be split without a name: IndexError, as in MerCat2 -- surfaces here)
     gz_writers.shutdown()
     if cleaned and args.debug:
         print(f"[debug] waited {round(timeit.default_timer() - wait_start, 2)} s more for the clean/*.fna.gz writers (gzip level 9)")

@@ -127,6 +127,7 @@ static void fold_pending(mk_ctx* c) {
 }
 
 static int pull_info(mk_ctx* c) {
+  if (c->clean_mode && c->clean_meta.p) MK_HIP(hipMemcpyAsync(c->h_clean, c->clean_meta.p, 8 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   MK_HIP(hipMemcpyAsync(c->h_info, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
   MK_HIP(hipStreamSynchronize(c->stream));
   fold_pending(c);  // (the stream is idle: whatever was in flight has landed)
@@ -187,8 +188,9 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
     return fail(MK_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   c->use_speculation = getenv("MK_NO_SPECULATION") ? 0 : 1;
   c->use_reuse = getenv("MK_NO_REUSE") ? 0 : 1;
-  if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo), hipHostMallocDefault)) != hipSuccess)
+  if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo) + 8 * sizeof(u64), hipHostMallocDefault)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  c->h_clean = (u64*)(c->h_info + 2);
   if ((rc = mk_buf_reserve(c, c->info, sizeof(MkChunkInfo) + 64)) != MK_OK) return fail(rc, c->err);
   if (c->mode == MK_MODE_DENSE) {
     const size_t bytes = ((size_t)1 << kb) * sizeof(u64);
@@ -212,7 +214,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
                      &c->run_ref, &c->arena, &c->run128, &c->ex128, &c->ex128_out, &c->ex_keys, &c->ex_cnts, &c->ex_keys2, &c->ex_cnts2, &c->ex_tmp, &c->part, &c->part_meta, &c->surv_keys, &c->surv_cnts, &c->surv_keys2,
-                     &c->xfer_out, &c->xfer_in, &c->xfer_meta};
+                     &c->xfer_out, &c->xfer_in, &c->xfer_meta, &c->clean_meta, &c->clean_runs};
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->ingest_ring) (void)hipHostFree(c->ingest_ring);
@@ -250,6 +252,7 @@ static int reset_impl(mk_ctx* c, size_t expect_rows) {
   c->in_chunk = false;
   c->raw_len = 0;
   c->part_reuse_ok = false;  // (a new sample sizes its own bucket regions: nothing is inherited across samples)
+  c->clean_n_runs = c->clean_n_bytes = c->clean_gc = c->clean_symbols = c->clean_raw = c->clean_headers = c->clean_last_runs = 0;
   MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
 }
@@ -272,6 +275,43 @@ extern "C" int mk_set_canonical(mk_ctx* c, int on) {
     }
   }
   c->canonical = on ? 1 : 0;
+  return MK_OK;
+}
+
+extern "C" int mk_set_clean(mk_ctx* c, int on, int toupper) {
+  if (!c) return MK_ERR_ARG;
+  if (on && c->alphabet != MK_ALPHABET_NT2) { c->err = "mk_set_clean: removeN applies to nucleotide FASTA (bin/mercat2.py:276)"; return MK_ERR_ARG; }
+  if (c->in_chunk) { c->err = "mk_set_clean: a chunk is open"; return MK_ERR_STATE; }
+  c->clean_mode = on ? 1 : 0;
+  c->clean_upper = (on && toupper) ? 1 : 0;
+  return MK_OK;
+}
+
+extern "C" int mk_clean_stats(mk_ctx* c, mk_clean_gpu_t* out) {
+  if (!c || !out) return MK_ERR_ARG;
+  out->raw_bytes = c->clean_raw;
+  out->symbols = c->clean_symbols;
+  out->gc_count = c->clean_gc;
+  out->n_bytes = c->clean_n_bytes;
+  out->n_runs = c->clean_n_runs;
+  out->header_lines = c->clean_headers;
+  out->last_runs = c->clean_last_runs;
+  return MK_OK;
+}
+
+extern "C" int mk_clean_runs(mk_ctx* c, uint64_t* starts, uint64_t* ends, size_t cap, size_t* n) {
+  if (!c || !n || (cap && (!starts || !ends))) return MK_ERR_ARG;
+  const size_t kept = std::min<size_t>((size_t)c->clean_last_runs, (size_t)1 << 16);
+  *n = kept;
+  if (!kept || !cap) return MK_OK;
+  MK_HIP(hipSetDevice(c->device));
+  std::vector<u64> a(kept), b(kept);
+  MK_HIP(hipMemcpyAsync(a.data(), c->clean_runs.p, kept * 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipMemcpyAsync(b.data(), (const u64*)c->clean_runs.p + ((size_t)1 << 16), kept * 8, hipMemcpyDeviceToHost, c->stream));
+  MK_HIP(hipStreamSynchronize(c->stream));
+  std::sort(a.begin(), a.end());  // (written in the order the waves got to them)
+  std::sort(b.begin(), b.end());
+  for (size_t i = 0; i < kept && i < cap; ++i) { starts[i] = a[i]; ends[i] = b[i]; }
   return MK_OK;
 }
 
@@ -481,7 +521,13 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
 // bytes in front; only the (rare) general-parser fallback needs an aligned copy.
 static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
   int rc;
-  if (c->use_speculation && c->use_fast_parse && c->alphabet == MK_ALPHABET_NT2 && n && n < 0xFE000000ull &&
+  if (c->clean_mode) {  // (one read-back more than the speculative lane: the chunk must be known to be reproducible BEFORE it is merged)
+    if (!c->use_fast_parse) { c->err = "clean mode needs the fast parser (MK_NO_FAST_PARSE is set)"; return MK_ERR_UNSUPPORTED; }
+    if (d_raw != (const uint8_t*)c->raw.p) { c->err = "clean mode rewrites the text in place: feed it (mk_chunk_feed), do not pass caller memory"; return MK_ERR_STATE; }
+    MK_HIP(hipSetDevice(c->device));
+    if ((rc = mk_launch_clean_pre(c, (uint8_t*)c->raw.p, n)) != MK_OK) return rc;
+  }
+  if (!c->clean_mode && c->use_speculation && c->use_fast_parse && c->alphabet == MK_ALPHABET_NT2 && n && n < 0xFE000000ull &&
       ((c->mode == MK_MODE_HASH64 && c->use_partition && c->use_superkmer && c->k >= 18 && c->k <= 32) ||
        (c->mode == MK_MODE_HASH128 && c->use_superkmer2))) {
     rc = process_chunk_fast(c, d_raw, n, min_count);
@@ -510,7 +556,29 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     }
     if ((rc = fast ? mk_launch_fparse(c, d_al, begin, n, fused) : mk_launch_parse(c, d_raw, n)) != MK_OK) return rc;
     if (packed && !fused && (rc = mk_launch_pack(c, n)) != MK_OK) return rc;
+    if (c->clean_mode && (rc = mk_launch_clean_post(c, n)) != MK_OK) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
+    if (c->clean_mode) {
+      const u64* m = c->h_clean;  // first header | '>' bytes | marker bytes in the input | N bytes | runs | G+C | starts | ends
+      const u64 headers = c->h_info->seq_len - c->h_info->symbols;
+      const char* why = c->h_info->parse_fallback ? "a blank inside a sequence line"
+                        : m[2]                    ? "a 0x7F byte in the text, or blanks in front of the first header"
+                        : m[1] != headers         ? "a '>' that does not start a header line"
+                                                  : nullptr;
+      if (why) {
+        c->err = std::string("clean mode: ") + why + " (removeN's rewrite of such text is not reproduced on the GPU; nothing was counted)";
+        return MK_ERR_UNSUPPORTED;
+      }
+      c->clean_raw += n;
+      c->clean_headers += headers;
+      c->clean_n_bytes += m[3];
+      c->clean_n_runs += m[4];
+      c->clean_gc += m[5];
+      c->clean_symbols += c->h_info->symbols - m[3];
+      c->clean_last_runs = m[4];
+      c->h_info->symbols -= m[3];  // (the N bytes are separators now)
+      break;
+    }
     if (!fast || !c->h_info->parse_fallback) break;
     // a blank inside a sequence line: the general transducer handles strip() exactly
     MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
@@ -658,7 +726,7 @@ extern "C" int mk_count_device(mk_ctx* c, const uint8_t* d_text, size_t n, uint6
   if (!c) return MK_ERR_ARG;
   if (c->in_chunk) { c->err = "mk_count_device: a chunk is open"; return MK_ERR_STATE; }
   if (n && !d_text) { c->err = "mk_count_device: d_text is NULL"; return MK_ERR_ARG; }
-  if (((uintptr_t)d_text & 15) == 0 || c->use_fast_parse) return process_chunk(c, d_text, n, min_count);
+  if (!c->clean_mode && (((uintptr_t)d_text & 15) == 0 || c->use_fast_parse)) return process_chunk(c, d_text, n, min_count);
   int rc = mk_chunk_begin(c);
   if (!rc) rc = mk_chunk_feed_device(c, d_text, n);
   if (rc) { c->in_chunk = false; return rc; }

@@ -166,6 +166,13 @@ struct mk_ctx {
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
   MkDevBuf ex128, ex128_out;  // two-word rows: compacted {hi, lo, count} + sort scratch; sorted rows for the host
 
+  // clean mode (mk_clean.hip): the raw file is counted as removeN would leave it
+  int clean_mode = 0, clean_upper = 0;
+  MkDevBuf clean_meta, clean_runs;
+  unsigned long long* h_clean = nullptr;   // pinned: the 8 meta words of the last chunk
+  unsigned long long clean_n_runs = 0, clean_n_bytes = 0, clean_gc = 0, clean_symbols = 0, clean_raw = 0, clean_headers = 0;
+  unsigned long long clean_last_runs = 0;  // runs of the last chunk (listed in clean_runs up to its capacity)
+
   // multi-GPU merge staging (mk_multi.hip): rows grouped by owner going out, rows received from the peers,
   // owner bounds + histogram + cursors
   MkDevBuf xfer_out, xfer_in, xfer_meta;
@@ -258,6 +265,10 @@ int mk_pull_info(mk_ctx* c);                   // MkChunkInfo -> h_info, stream 
 int mk_grow_run(mk_ctx* c, size_t more_rows);  // room in the packed running table for more_rows further keys
 // mk_table.hip: interleaved rows {key word(s), count} -> running table (dense: {bin, count})
 int mk_launch_import_rows(mk_ctx* c, const uint64_t* d_rows, size_t rows);
+
+// mk_clean.hip
+int mk_launch_clean_pre(mk_ctx* c, uint8_t* d_raw, size_t n);
+int mk_launch_clean_post(mk_ctx* c, size_t seq_cap);
 
 void mk_prof_begin(mk_ctx* c, int id);
 void mk_prof_end(mk_ctx* c);

@@ -40,6 +40,38 @@ def _write_clean_gz(out_fasta: Path, cleaned, timings: Optional[dict] = None) ->
     return os.stat(out_fasta).st_size
 
 
+def removeN_background(fasta: Path, raw, outpath: Path, toupper: bool, writers, timings: Optional[dict] = None):
+    """The whole of removeN -- rewrite and ``<base>_clean.fna.gz`` -- on the executor ``writers``, from the file's bytes
+    ``raw`` already in memory: for samples whose table the GPU takes from the raw text (harness.run_raw_clean), so that
+    nothing of removeN stands in front of the first kernel.  Returns ``(path, future, holder)``; ``future.result()`` is
+    ``(size of the finished .gz, stats)``; the cleaned bytes are left in ``holder["text"]`` unless the caller has
+    called ``holder["drop"]()`` (it did not need them: no reason to keep a second copy of the sample in memory)."""
+    import threading
+    os.makedirs(outpath, exist_ok=True)
+    basename = Path(fasta).stem.split(".")[0]
+    out_fasta = Path(outpath, f"{basename}_clean.fna.gz")
+    lock = threading.Lock()
+    holder = {"dropped": False}
+
+    def drop():
+        with lock:
+            holder["dropped"] = True
+            holder.pop("text", None)
+    holder["drop"] = drop
+
+    def job():
+        import timeit
+        t0 = timeit.default_timer()
+        cleaned, stats = clean_text(raw, toupper)
+        if timings is not None:
+            timings["clean_s"] = timeit.default_timer() - t0
+        with lock:
+            if not holder["dropped"]:
+                holder["text"] = cleaned
+        return _write_clean_gz(out_fasta, cleaned, timings), stats
+    return out_fasta.absolute(), writers.submit(job), holder
+
+
 def removeN_start(fasta: Path, outpath: Path, toupper: bool, writers, timings: Optional[dict] = None):
     """removeN with the level-9 DEFLATE off the critical path: the file is read and rewritten (native code, memory
     speed) here; writing ``<base>_clean.fna.gz`` -- ~1.5 MB/s of zlib on DNA, a hundred times slower than everything

@@ -180,6 +180,63 @@ def run_text(basename: str, text, out_file, kmer: int, min_count: int, chunk_mib
             _give_back(c, (kmer, alphabet, c.device, canon), size)
 
 
+def run_raw_clean(basename: str, raw, out_file, kmer: int, min_count: int, toupper: bool, limit_bytes: int = 0,
+                  *, device: int = 0, canonical: bool = False, report=print, keep: Optional[dict] = None,
+                  timings: Optional[dict] = None) -> Optional[Tuple[str, Optional[os.PathLike]]]:
+    """The table of a nucleotide sample straight from its RAW text, counted as removeN would leave it (mk_set_clean:
+    N runs cut records, text in front of the first header dropped, ``toupper`` after the cut) -- without waiting for
+    the host's rewrite and the gzip of ``<base>_clean.fna.gz``.  Only for a sample that is ONE chunk: ``limit_bytes``
+    (the -s size, 0 = never chunked) is compared with an upper bound of the cleaned text's size made of the GPU's own
+    figures (every N run adds one header line).  Returns None -- nothing counted, nothing written -- when the sample may
+    be chunked or holds text the GPU mode does not reproduce; the caller then counts the text removeN produced."""
+    import timeit
+    mv = memoryview(raw)
+    if limit_bytes and len(mv) + len(mv) // 50 + 4096 >= limit_bytes:
+        return None
+    canon = bool(canonical)
+    key = (kmer, native.ALPHABET_NT2, device, canon)
+    ctx = _take_context(*key)
+    size = 1 << 62
+    t0 = timeit.default_timer()
+    try:
+        ctx.set_clean(True, toupper)
+        try:
+            ctx.count_chunk(mv, min_count)
+        except native.CleanUnsupported:
+            ctx.reset()
+            size = len(mv)
+            return None
+        st = ctx.clean_stats()
+        # cleaned size <= raw + (one header line per N run, none longer than all non-sequence bytes together) + re-wrapping
+        bound = len(mv) + st["n_runs"] * ((len(mv) - st["symbols"] - st["n_bytes"]) + 16) + len(mv) // 40 + 64
+        if limit_bytes and bound >= limit_bytes:
+            ctx.reset()
+            size = len(mv)
+            return None
+        t1 = timeit.default_timer()
+        result = _finish(ctx, basename, out_file, report)
+        size = len(mv)
+        if timings is not None:
+            timings.update(count_s=t1 - t0, tsv_s=timeit.default_timer() - t1, chunks=1, contexts=1, devices=1, gpu_clean=1,
+                           n_runs=st["n_runs"], gc_gpu=round(100.0 * st["gc_count"] / max(1, st["symbols"]), 4))
+        if keep is not None and result[1] is not None:
+            ctx.set_clean(False)
+            ctx.trim()
+            keep[basename] = ctx
+            ctx = None
+        return result
+    except BaseException:
+        size = 1 << 62
+        raise
+    finally:
+        if ctx is not None:
+            try:
+                ctx.set_clean(False)
+            except native.MercatHipError:
+                size = 1 << 62
+            _give_back(ctx, key, size)
+
+
 # a file that is ONE filter unit is only spread over several GPUs from this size on (mk_count_file: MK_SPLIT_MIN)
 SPLIT_MIN_BYTES = 64 << 20
 

@@ -18,7 +18,7 @@ MODE_NAMES = {0: "dense", 1: "hash64", 2: "hash128", 3: "byref"}
 
 MK_OK = 0
 ERR_NAMES = {-1: "MK_ERR_ARG", -2: "MK_ERR_HIP", -3: "MK_ERR_NOMEM", -4: "MK_ERR_STATE",
-             -5: "MK_ERR_NON_ASCII", -6: "MK_ERR_IO", -7: "MK_ERR_RANGE"}
+             -5: "MK_ERR_NON_ASCII", -6: "MK_ERR_IO", -7: "MK_ERR_RANGE", -8: "MK_ERR_UNSUPPORTED"}
 
 # every symbol include/mercat_hip.h declares (tests check the library exports each of them)
 ABI_SYMBOLS = [
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mk_filter_min", "mk_remove_n", "mk_free", "mk_write_merged_tsv_t", "mk_write_merged_tsv_as_reference",
     "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
     "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
-    "mk_device_count", "mk_reset_for", "mk_textwrap",
+    "mk_device_count", "mk_reset_for", "mk_textwrap", "mk_set_clean", "mk_clean_stats", "mk_clean_runs",
 ]
 MK_ABI = 3  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
 MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED = 0, 1, 2
@@ -45,6 +45,11 @@ class MercatHipError(RuntimeError):
 
 class NonAsciiInput(MercatHipError, UnicodeDecodeError.__base__):  # ValueError family, like a decode error
     pass
+
+
+class CleanUnsupported(MercatHipError):
+    """Clean mode (Counter.set_clean): the text holds something whose rewrite by removeN the GPU does not reproduce;
+    nothing was counted -- count the text mk_remove_n produces instead."""
 
 
 class Stats(C.Structure):
@@ -68,6 +73,11 @@ class FileStats(C.Structure):
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
+
+
+class CleanGpu(C.Structure):
+    """mk_clean_gpu_t (include/mercat_hip.h)."""
+    _fields_ = [(n, C.c_uint64) for n in ("raw_bytes", "symbols", "gc_count", "n_bytes", "n_runs", "header_lines", "last_runs")]
 
 
 class MergeStats(C.Structure):
@@ -117,6 +127,9 @@ def lib() -> C.CDLL:
         "mk_reset": (C.c_int, [vp]),
         "mk_reset_for": (C.c_int, [vp, C.c_uint64]),
         "mk_set_canonical": (C.c_int, [vp, C.c_int]),
+        "mk_set_clean": (C.c_int, [vp, C.c_int, C.c_int]),
+        "mk_clean_stats": (C.c_int, [vp, C.POINTER(CleanGpu)]),
+        "mk_clean_runs": (C.c_int, [vp, u64p, u64p, C.c_size_t, szp]),
         "mk_chunk_begin": (C.c_int, [vp]),
         "mk_chunk_feed": (C.c_int, [vp, u8p, C.c_size_t]),
         "mk_chunk_feed_device": (C.c_int, [vp, u8p, C.c_size_t]),
@@ -479,7 +492,7 @@ class Counter:
         if rc:
             msg = self._L.mk_last_error(self._h)
             text = msg.decode() if msg else ""
-            raise (NonAsciiInput if rc == -5 else MercatHipError)(rc, text)
+            raise (NonAsciiInput if rc == -5 else CleanUnsupported if rc == -8 else MercatHipError)(rc, text)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -502,6 +515,26 @@ class Counter:
     def set_canonical(self, on: bool):
         """Opt-in extension (not reference behaviour): count min(kmer, reverse complement)."""
         self._check(self._L.mk_set_canonical(self._h, 1 if on else 0))
+
+    def set_clean(self, on: bool, toupper: bool = False):
+        """Count RAW nucleotide FASTA as removeN would leave it (mk_set_clean): N runs cut records, text in front of the
+        first header is dropped, -toupper applies after the cut.  One chunk per file; CleanUnsupported when the text
+        holds something the GPU does not reproduce."""
+        self._check(self._L.mk_set_clean(self._h, 1 if on else 0, 1 if toupper else 0))
+
+    def clean_stats(self) -> dict:
+        st = CleanGpu()
+        self._check(self._L.mk_clean_stats(self._h, C.byref(st)))
+        return {n: int(getattr(st, n)) for n, _ in st._fields_}
+
+    def clean_runs(self) -> Tuple[np.ndarray, np.ndarray]:
+        """The N runs of the last chunk as (starts, ends) in the parsed stream (mk_clean_runs)."""
+        n = C.c_size_t(0)
+        self._check(self._L.mk_clean_runs(self._h, None, None, 0, C.byref(n)))
+        a, b = np.empty(n.value, dtype=np.uint64), np.empty(n.value, dtype=np.uint64)
+        if n.value:
+            self._check(self._L.mk_clean_runs(self._h, a.ctypes.data, b.ctypes.data, n.value, C.byref(n)))
+        return a, b
 
     def reset(self, expect_rows: int = 0):
         """Forget the running table; with ``expect_rows`` also size it for about that many keys if that is less than
