@@ -252,6 +252,7 @@ static int reset_impl(mk_ctx* c, size_t expect_rows) {
   c->in_chunk = false;
   c->raw_len = 0;
   c->part_reuse_ok = false;  // (a new sample sizes its own bucket regions: nothing is inherited across samples)
+  c->dup_known = false;
   c->clean_n_runs = c->clean_n_bytes = c->clean_gc = c->clean_symbols = c->clean_raw = c->clean_headers = c->clean_last_runs = 0;
   MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
@@ -499,7 +500,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   MK_HIP(hipMemcpyAsync(c->h_info + 1, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
   c->pending_rows = true;
   if (h->side && h->side >= min_count) c->run_side += h->side;
-  if (h->distinct) c->dup_hint = (double)h->windows / (double)h->distinct;
+  if (h->distinct) { c->dup_hint = (double)h->windows / (double)h->distinct; c->dup_known = true; }
   if (h->records) c->nk_hint = (double)(h->windows + h->exotic) / (double)h->records;
   if (getenv("MK_VERBOSE"))
     fprintf(stderr, "[mk] chunk (one read-back): raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu p1=2^%d dup=%.2f nk=%.2f\n",
@@ -693,7 +694,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
   if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
-  if (sk2 && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
+  if (sk2 && c->h_info->distinct) { c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct; c->dup_known = true; }
   if ((partitioned || sk2) && c->h_info->records)
     c->nk_hint = (double)(c->h_info->windows + c->h_info->exotic) / (double)c->h_info->records;
 

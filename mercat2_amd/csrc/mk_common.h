@@ -146,6 +146,7 @@ struct mk_ctx {
   int use_superkmer2 = 1;
   int p1_log2 = 10;
   double dup_hint = 1.0;  // windows per distinct key seen in the previous chunk
+  bool dup_known = false; // ... of THIS sample (mk_reset forgets it)
   int use_partition = 1;
   int use_fast_parse = 1;
   int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)

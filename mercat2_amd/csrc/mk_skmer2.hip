@@ -566,6 +566,239 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
   }
 }
 
+// ------------------------------------------------------------------- count with a counting pre-filter
+// When min_count is well above the mean count of a key -- BASELINE config 5: S3 at -c 10, a chunk covers its genome
+// 1.9 times, 43 M of its 57 M windows are keys seen once -- nearly every insert of the kernel above is wasted: the key
+// goes into the table (lock, 16-byte write, publish), forces a second sub-range pass because 5 250 distinct keys do not
+// fit 6 144 slots at 60 %, and is thrown away by the emit sweep.  Here every (sub-range) pass runs TWICE over the
+// bucket's records:
+//   P  every key adds 1 to ONE of 16 384 32-bit counters in LDS (index = bits of a hash of the key): a count-min row.
+//      A counter is never below the count of any key that maps to it.
+//   Q  the keys whose counter reached min_count -- candidates: all keys that can survive, plus a few that share a
+//      counter with others -- are inserted into a small exact table (2 048 slots), every occurrence of them, so the
+//      counts the emit sweep sees are exact; the rest is dropped after one LDS read.
+// No key is written, nothing is locked, and the bucket needs no sub-range split (the counters have no capacity to
+// overflow; the candidates' table overflows only if thousands of keys reach min_count, and then splits as above).
+// `distinct` is the number of counters in use (keys that share a counter count once: a lower bound).
+#define SK2P_CNT 16384
+#define SK2P_SLOTS 2048
+#define SK2P_MAX_PROBE 64
+
+// 32-bit hash for the counters and the sub-range: the 128 key bits folded to 64, then three 24-bit multiplies
+__device__ __forceinline__ unsigned sk2p_hash(u64 hi, u64 lo) {
+  const u64 f = hi ^ ((lo >> 23) | (lo << 41));  // (no 64-bit multiply: a quarter-rate v_mul_lo_u32 each)
+  const unsigned a = (unsigned)f, b = (unsigned)(f >> 32);
+  unsigned h = __umul24(a, 0x9E3779u) ^ __umul24(__funnelshift_r(a, b, 24), 0x85EBCBu) ^ __umul24(b >> 16, 0xC2B2AFu);
+  return h ^ (h >> 15);
+}
+
+__device__ __forceinline__ void sk2p_insert(ulonglong2* tkey, unsigned* tcnt, unsigned* ovf, u64 hi, u64 lo, unsigned h) {
+  unsigned slot = (unsigned)(((u64)h * SK2P_SLOTS) >> 32);
+  bool done = false;
+#pragma unroll 1
+  for (int probe = 0; probe < SK2P_MAX_PROBE && !done;) {
+    unsigned c = __hip_atomic_load(&tcnt[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (c == 0) {
+      c = atomicCAS(&tcnt[slot], 0u, SK2C_LOCK);
+      if (c == 0) {
+        tkey[slot] = make_ulonglong2(hi, lo);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicAdd(&tcnt[slot], 1u - SK2C_LOCK);
+        done = true;
+      }
+    }
+    if (!done && !(c & SK2C_LOCK)) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const ulonglong2 o = tkey[slot];
+      if (o.x == hi && o.y == lo) {
+        atomicAdd(&tcnt[slot], 1u);
+        done = true;
+      } else {
+        slot = slot + 1 == SK2P_SLOTS ? 0u : slot + 1;
+        ++probe;
+      }
+    }
+  }
+  if (!done) atomicOr(ovf, 1u);
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
+                                                                u64* __restrict__ cursor,
+                                                                const u64* __restrict__ kstart, u64* __restrict__ nsurv,
+                                                                MkChunkInfo* __restrict__ info, u64 min_count,
+                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
+                                                                u64* __restrict__ out_cnt, int k, unsigned p1) {
+  __shared__ unsigned cnt32[SK2P_CNT];
+  __shared__ __attribute__((aligned(16))) ulonglong2 tkey[SK2P_SLOTS];
+  __shared__ unsigned tcnt[SK2P_SLOTS];
+  __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
+  __shared__ unsigned long long s_windows;
+  __shared__ unsigned s_abort;
+  if (threadIdx.x == 0) { s_abort = info->part_overflow != 0; s_windows = 0; }
+  __syncthreads();
+  if (s_abort) return;
+  for (unsigned i = threadIdx.x; i < SK2P_CNT; i += blockDim.x) cnt32[i] = 0;
+  for (unsigned i = threadIdx.x; i < SK2P_SLOTS; i += blockDim.x) tcnt[i] = 0;
+  if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
+  __syncthreads();
+  unsigned par = 0;
+  const int lane = threadIdx.x & 63;
+  const u64 lomask = (k >= 64) ? ~0ull : (~0ull << (128 - 2 * k));
+  const unsigned need = min_count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)min_count;
+  u64 distinct_total = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
+  for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
+    const u64 lo_r = start[b], n = cursor[b] - lo_r;
+    u64* __restrict__ my_hi = out_hi + kstart[b];
+    u64* __restrict__ my_lo = out_lo + kstart[b];
+    u64* __restrict__ my_cnt = out_cnt + kstart[b];
+    const u64 region = kstart[b + 1] - kstart[b];
+    unsigned emitted = 0;
+    bool counted = false;
+    records_total += n;
+    if (n >> 27) {
+      ++nerr;
+    } else if (n) {
+      int s = 0;
+      unsigned idx = 0;
+      const Sk2Rec* __restrict__ src = part + lo_r;
+      for (;;) {
+        const unsigned sel_shift = 32 - s;  // the sub-range is picked by the TOP bits of the hash, the counter by the low ones
+        unsigned* const ovf = &s_overflow[par];
+        u64 win_pass = 0;
+        // ---- P: count every key of the sub-range into its counter
+        for (u64 jb = 0; jb < n; jb += SK2C_THREADS) {
+          const u64 j = jb + threadIdx.x;
+          Sk2Rec rec;
+          rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
+          if (j < n) rec = src[j];
+          const int nk = (int)rec.nk;
+          win_pass += counted ? 0 : (u64)nk;
+          u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            u64 khi = x0, klo = x1 & lomask;
+            if constexpr (CANON) sk2_canon128(khi, klo, k);
+            x0 = (x0 << 2) | (x1 >> 62);
+            x1 = (x1 << 2) | (x2 >> 62);
+            x2 <<= 2;
+            const unsigned h = sk2p_hash(khi, klo);
+            if (u < nk && (!s || (h >> sel_shift) == idx)) atomicAdd(&cnt32[h & (SK2P_CNT - 1)], 1u);
+          }
+        }
+        __syncthreads();  // P done: the counters are final
+        // ---- Q: the candidates into the exact table
+        for (u64 jb = 0; jb < n; jb += SK2C_THREADS) {
+          const u64 j = jb + threadIdx.x;
+          Sk2Rec rec;
+          rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
+          if (j < n) rec = src[j];
+          const int nk = (int)rec.nk;
+          u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
+          unsigned cv[SK2_NKMAX];
+          u64 khi[SK2_NKMAX], klo[SK2_NKMAX];
+          unsigned cand = 0;
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) {
+            khi[u] = x0;
+            klo[u] = x1 & lomask;
+            if constexpr (CANON) sk2_canon128(khi[u], klo[u], k);
+            x0 = (x0 << 2) | (x1 >> 62);
+            x1 = (x1 << 2) | (x2 >> 62);
+            x2 <<= 2;
+            const unsigned h = sk2p_hash(khi[u], klo[u]);
+            const bool mine = u < nk && (!s || (h >> sel_shift) == idx);
+            cv[u] = mine ? cnt32[h & (SK2P_CNT - 1)] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < SK2_NKMAX; ++u) cand |= (cv[u] >= need && cv[u]) ? (1u << u) : 0u;
+          if (cand) {  // (rare: one lane in a hundred at -c 10)
+#pragma unroll 1
+            for (int u = 0; u < SK2_NKMAX; ++u)
+              if ((cand >> u) & 1u) sk2p_insert(tkey, tcnt, ovf, khi[u], klo[u], sk2c_hash(khi[u], klo[u]));
+          }
+        }
+        __syncthreads();  // A: every insert of the pass is in the table
+        if (threadIdx.x == 0) cursor[b] = lo_r;  // back to the region's start: the next chunk may inherit the regions
+        const bool over = s_overflow[par] != 0;
+        if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
+        {
+          // counters: how many are in use (the distinct keys, less those that share one), and clear
+          unsigned occ = 0;
+#pragma unroll
+          for (int q = 0; q < SK2P_CNT / SK2C_THREADS; q += 4) {
+            const unsigned i = (q * SK2C_THREADS + 4 * threadIdx.x);
+            const uint4 c4 = *reinterpret_cast<const uint4*>(&cnt32[i]);
+            occ += (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
+            *reinterpret_cast<uint4*>(&cnt32[i]) = make_uint4(0u, 0u, 0u, 0u);
+          }
+          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
+          // exact table: emit what reached min_count, clear
+          constexpr int PER = SK2P_SLOTS / SK2C_THREADS;
+          unsigned ec[PER];
+          unsigned mine = 0;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const unsigned i = q * SK2C_THREADS + threadIdx.x;
+            ec[q] = tcnt[i];
+            tcnt[i] = 0;
+            if (over || (u64)ec[q] < min_count) ec[q] = 0;
+            mine += ec[q] != 0;
+          }
+          if (mine) {
+            const unsigned at = emitted + atomicAdd(&s_emit[par], mine);
+            unsigned o = 0;
+            if ((u64)at + mine > region) {
+              atomicOr(&info->part_overflow, 8ull);
+              mine = 0;
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              if (mine && ec[q]) {
+                const ulonglong2 key = tkey[q * SK2C_THREADS + threadIdx.x];
+                my_hi[at + o] = key.x;
+                my_lo[at + o] = key.y;
+                my_cnt[at + o] = ec[q];
+                ++o;
+              }
+            }
+          }
+        }
+        __syncthreads();  // B
+        emitted += s_emit[par];
+        distinct_total += s_distinct[par];
+        par ^= 1;
+        if (over) {  // thousands of candidates: split the hash range and take the halves one after the other
+          if (s >= 16) { ++nerr; break; }
+          s += 1;
+          idx <<= 1;
+        } else {
+          windows += win_pass;
+          counted = true;
+          while (s > 0 && (idx & 1u)) { idx >>= 1; --s; }
+          if (s == 0) break;
+          ++idx;
+        }
+      }
+    }
+    if (threadIdx.x == 0) nsurv[b] = emitted;
+    survivors_total += emitted;
+  }
+  {
+    for (int d = 32; d > 0; d >>= 1) windows += __shfl_down(windows, d);
+    if (lane == 0 && windows) atomicAdd(&s_windows, (unsigned long long)windows);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (s_windows) atomicAdd(&info->windows, (u64)s_windows);
+    if (records_total) atomicAdd(&info->records, records_total);
+    if (distinct_total) atomicAdd(&info->distinct, distinct_total);
+    if (survivors_total) atomicAdd(&info->survivors, survivors_total);
+    if (nerr) atomicAdd(&info->errors, nerr);
+  }
+}
+
 // ------------------------------------------------------------------------------------ launcher
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact) {
   if (seq_len == 0) return MK_OK;
@@ -640,7 +873,20 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     int ncu = 256;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
     const unsigned grid = (unsigned)((size_t)ncu < p1 ? (size_t)ncu : p1);
-    if (c->canonical)
+    // the counting pre-filter pays when few keys can reach min_count: min_count well above the mean count of a key,
+    // which the chunk before has measured (windows / distinct keys); a sample's first chunk takes the exact kernel
+    static const bool no_pre = getenv("MK_NO_PREFILTER") != nullptr;
+    static const bool force_pre = getenv("MK_FORCE_PREFILTER") != nullptr;
+    const bool pre = !no_pre && min_count >= 2 && (force_pre || (min_count >= 4 && c->dup_known && c->dup_hint * 2.5 < (double)min_count));
+    if (pre && c->canonical)
+      hipLaunchKernelGGL(mk_sk2_countp_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
+                         (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1);
+    else if (pre)
+      hipLaunchKernelGGL(mk_sk2_countp_k<false>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
+                         (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1);
+    else if (c->canonical)
       hipLaunchKernelGGL(mk_sk2_count_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
                          (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
                          (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
