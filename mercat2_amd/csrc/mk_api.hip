@@ -693,7 +693,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   else c->run_rows += (size_t)c->h_info->new_rows;
   c->run_ref_rows += (size_t)c->h_info->new_rows_ref;
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
-  if (partitioned && c->h_info->distinct) c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct;
+  if (partitioned && c->h_info->distinct) { c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct; c->dup_known = true; }
   if (sk2 && c->h_info->distinct) { c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct; c->dup_known = true; }
   if ((partitioned || sk2) && c->h_info->records)
     c->nk_hint = (double)(c->h_info->windows + c->h_info->exotic) / (double)c->h_info->records;

@@ -897,6 +897,223 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   if (K32) wave_add(&info->side, side);
 }
 
+// ------------------------------------------------------------------- count with a counting pre-filter
+// With -c well above the mean count of a key (S2: 75 M windows over 19.6 M distinct keys per chunk, -c 10) nearly every
+// insert of the kernel above -- compare-and-swap of the 64-bit key, add, deferred-key stack -- feeds a slot that the
+// emit sweep throws away.  Here every bucket is walked twice (as in mk_skmer2.hip, where the case is made at length):
+//   P  every key adds 1 to one of 16 384 32-bit counters in LDS (a count-min row): never below the count of a key that
+//      maps to it;
+//   Q  keys whose counter reached min_count (every key that can survive, plus the few that share a counter) are
+//      inserted into a small exact table, every occurrence of them; the rest costs one LDS read.
+// `distinct` = counters in use (a lower bound).
+// MEASURED (round 3, S2 chunk, k = 31, -c 10): 437 us against the exact kernel's 300 -- for one-word keys the tuned
+// single pass (compare-and-swap as soon as a slot is known, deferred-key stacks, the next bucket's records prefetched)
+// beats two plain passes; it is the two-word kernel, with its lock / write / publish protocol and its sub-range passes,
+// that the pre-filter more than halves (mk_skmer2.hip).  So this kernel is NOT the default: MK_FORCE_PREFILTER=1 selects
+// it (tests keep it exact: tests/test_gpu_parity.py::test_counting_prefilter_kernels_are_exact).
+#define SKP_CNT 16384
+#define SKP_SLOTS 2048
+#define SKP_MAX_PROBE 64
+
+__device__ __forceinline__ void skp_insert(u64* tkey, unsigned* tcnt, unsigned* ovf, u64 key, unsigned h) {
+  unsigned slot = h >> (32 - 11);  // SKP_SLOTS = 2^11
+  bool done = false;
+#pragma unroll 1
+  for (int probe = 0; probe < SKP_MAX_PROBE && !done; ++probe) {
+    u64 cur = tkey[slot];
+    if (cur == MK_EMPTY) {
+      cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
+      if (cur == MK_EMPTY) cur = key;
+    }
+    if (cur == key) {
+      atomicAdd(&tcnt[slot], 1u);
+      done = true;
+    } else {
+      slot = (slot + 1) & (SKP_SLOTS - 1);
+    }
+  }
+  if (!done) atomicOr(ovf, 1u);
+}
+
+template <bool CANON, bool K32>
+__global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
+                                                              u64* __restrict__ cursor, const u64* __restrict__ kstart,
+                                                              u64* __restrict__ nsurv, MkChunkInfo* __restrict__ info, u64 min_count,
+                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts, int k, unsigned p1) {
+  __shared__ unsigned cnt32[SKP_CNT];
+  __shared__ __attribute__((aligned(16))) u64 tkey[SKP_SLOTS];
+  __shared__ unsigned tcnt[SKP_SLOTS];
+  __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
+  __shared__ unsigned long long s_windows;
+  __shared__ unsigned s_abort;
+  if (threadIdx.x == 0) { s_abort = info->part_overflow != 0; s_windows = 0; }
+  __syncthreads();
+  if (s_abort) return;
+  for (unsigned i = threadIdx.x; i < SKP_CNT; i += blockDim.x) cnt32[i] = 0;
+  for (unsigned i = threadIdx.x; i < SKP_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
+  if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; }
+  __syncthreads();
+  unsigned par = 0;
+  const int kshift = 64 - 2 * k;
+  const int lane = threadIdx.x & 63;
+  const unsigned need = min_count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)min_count;
+  u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
+  for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
+    const u64 lo = start[b], n = cursor[b] - lo;
+    u64* __restrict__ my_keys = out_keys + kstart[b];
+    u64* __restrict__ my_cnts = out_cnts + kstart[b];
+    const u64 region = kstart[b + 1] - kstart[b];
+    unsigned emitted = 0;
+    bool counted = false;
+    records_total += n;
+    if (n >> 27) {  // 2^27 records x 31 k-mers would overflow the 32-bit LDS counters
+      ++nerr;
+    } else if (n) {
+      int s = 0;
+      unsigned idx = 0;
+      const ulonglong2* __restrict__ src = part + lo;
+      for (;;) {
+        const unsigned sel_shift = 32 - s;
+        unsigned* const ovf = &s_overflow[par];
+        u64 win_pass = 0, side_pass = 0;
+        // ---- P
+        for (u64 jb = 0; jb < n; jb += SKC_THREADS) {
+          const u64 j = jb + threadIdx.x;
+          const ulonglong2 rec = j < n ? src[j] : make_ulonglong2(0, 0);
+          const int nk = (int)(rec.y & 63);
+          win_pass += counted ? 0 : (u64)nk;
+          u64 x = rec.x, y = rec.y;
+          u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
+#pragma unroll
+          for (int u = 0; u < SKC_B; ++u) {
+            const u64 fw = x >> kshift;
+            const u64 key = (CANON && rcv < fw) ? rcv : fw;
+            x = (x << 2) | (y >> 62);
+            y <<= 2;
+            if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
+            const unsigned h = skc_hash(key);
+            bool on = u < nk && (!s || (h >> sel_shift) == idx);
+            if (K32 && key == MK_EMPTY) on = false;
+            if (on) atomicAdd(&cnt32[h & (SKP_CNT - 1)], 1u);
+          }
+        }
+        __syncthreads();
+        // ---- Q
+        for (u64 jb = 0; jb < n; jb += SKC_THREADS) {
+          const u64 j = jb + threadIdx.x;
+          const ulonglong2 rec = j < n ? src[j] : make_ulonglong2(0, 0);
+          const int nk = (int)(rec.y & 63);
+          u64 x = rec.x, y = rec.y;
+          u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
+          u64 kk[SKC_B];
+          unsigned hh[SKC_B];
+          unsigned cand = 0;
+#pragma unroll
+          for (int u = 0; u < SKC_B; ++u) {
+            const u64 fw = x >> kshift;
+            kk[u] = (CANON && rcv < fw) ? rcv : fw;
+            x = (x << 2) | (y >> 62);
+            y <<= 2;
+            if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
+            hh[u] = skc_hash(kk[u]);
+            bool on = u < nk && (!s || (hh[u] >> sel_shift) == idx);
+            if (K32 && on && kk[u] == MK_EMPTY) {
+              side_pass += counted ? 0 : 1;
+              on = false;
+            }
+            const unsigned cv = on ? cnt32[hh[u] & (SKP_CNT - 1)] : 0u;
+            cand |= (cv >= need && cv) ? (1u << u) : 0u;
+          }
+          if (cand) {
+#pragma unroll 1
+            for (int u = 0; u < SKC_B; ++u)
+              if ((cand >> u) & 1u) skp_insert(tkey, tcnt, ovf, kk[u], hh[u] * 0x9E3779B1u);
+          }
+        }
+        __syncthreads();  // A
+        if (threadIdx.x == 0) cursor[b] = lo;
+        const bool over = s_overflow[par] != 0;
+        if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
+        {
+          unsigned occ = 0;
+#pragma unroll
+          for (int q = 0; q < SKP_CNT / SKC_THREADS; q += 4) {
+            const unsigned i = (q * SKC_THREADS + 4 * threadIdx.x);
+            const uint4 c4 = *reinterpret_cast<const uint4*>(&cnt32[i]);
+            occ += (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
+            *reinterpret_cast<uint4*>(&cnt32[i]) = make_uint4(0u, 0u, 0u, 0u);
+          }
+          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
+          constexpr int PER = SKP_SLOTS / SKC_THREADS;
+          unsigned ec[PER];
+          unsigned mine = 0;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const unsigned i = q * SKC_THREADS + threadIdx.x;
+            ec[q] = tcnt[i];
+            if (over || (u64)ec[q] < min_count) ec[q] = 0;
+            mine += ec[q] != 0;
+          }
+          if (mine) {
+            const unsigned at = emitted + atomicAdd(&s_emit[par], mine);
+            unsigned o = 0;
+            if ((u64)at + mine > region) {
+              atomicOr(&info->part_overflow, 8ull);
+              mine = 0;
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {
+              if (mine && ec[q]) {
+                my_keys[at + o] = tkey[q * SKC_THREADS + threadIdx.x];
+                my_cnts[at + o] = ec[q];
+                ++o;
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const unsigned i = q * SKC_THREADS + threadIdx.x;
+            tkey[i] = MK_EMPTY;
+            tcnt[i] = 0;
+          }
+        }
+        __syncthreads();  // B
+        emitted += s_emit[par];
+        distinct_total += s_distinct[par];
+        par ^= 1;
+        if (over) {
+          if (s >= 16) { ++nerr; break; }
+          s += 1;
+          idx <<= 1;
+        } else {
+          windows += win_pass;
+          side += side_pass;
+          counted = true;
+          while (s > 0 && (idx & 1u)) { idx >>= 1; --s; }
+          if (s == 0) break;
+          ++idx;
+        }
+      }
+    }
+    if (threadIdx.x == 0) nsurv[b] = emitted;
+    survivors_total += emitted;
+  }
+  {
+    for (int d = 32; d > 0; d >>= 1) windows += __shfl_down(windows, d);
+    if (lane == 0 && windows) atomicAdd(&s_windows, (unsigned long long)windows);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (s_windows) atomicAdd(&info->windows, (u64)s_windows);
+    if (records_total) atomicAdd(&info->records, records_total);
+    if (distinct_total) atomicAdd(&info->distinct, distinct_total);
+    if (survivors_total) atomicAdd(&info->survivors, survivors_total);
+    if (nerr) atomicAdd(&info->errors, nerr);
+  }
+  if (K32) wave_add(&info->side, side);
+}
+
 #ifdef SK_EXP_SORT
 // EXPERIMENT (timing only, not in the product build): the records of every bucket sorted by their number of windows,
 // longest first (classes = 8: every length its own class; classes = 2: five windows or more first) -- what a scatter
@@ -1081,6 +1298,17 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     dbgbuf = mk_dbg_ptr;
 #endif
     const int dflags = getenv("MK_DBG") ? atoi(getenv("MK_DBG")) : 0;
+    static const bool no_pre = getenv("MK_NO_PREFILTER") != nullptr;
+    static const bool force_pre = getenv("MK_FORCE_PREFILTER") != nullptr;
+    const bool pre = !no_pre && !exact && min_count >= 2 && nkmax <= SKC_B && force_pre;  // (opt-in only: see mk_sk_countp_k)
+#define SKP_LAUNCH(CANON, K32)                                                                                          \
+  hipLaunchKernelGGL((mk_sk_countp_k<CANON, K32>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
+                     (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
+                     (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, k, (unsigned)p1)
+    if (pre) {
+      if (c->canonical) { if (k == 32) SKP_LAUNCH(true, true); else SKP_LAUNCH(true, false); }
+      else { if (k == 32) SKP_LAUNCH(false, true); else SKP_LAUNCH(false, false); }
+    } else {
 #define SKC_LAUNCH(CANON, K32)                                                                                          \
   hipLaunchKernelGGL((mk_sk_count_k<CANON, K32>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
                      (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
@@ -1088,6 +1316,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     if (c->canonical) { if (k == 32) SKC_LAUNCH(true, true); else SKC_LAUNCH(true, false); }
     else { if (k == 32) SKC_LAUNCH(false, true); else SKC_LAUNCH(false, false); }
 #undef SKC_LAUNCH
+    }
+#undef SKP_LAUNCH
   }
   mk_prof_end(c);
 #ifdef MK_STAMP

@@ -909,3 +909,32 @@ def test_input_shapes_vs_c_oracle():
             okm, ocn = c_oracle.count(data, k, c)
             assert np.array_equal(kmers, okm) and np.array_equal(counts, ocn), (name, k, c)
             assert dt < 2.0, (name, k, dt)
+
+
+@pytest.mark.parametrize("k,c,genome,reads", [(63, 10, 400_000, 60_000), (33, 4, 400_000, 60_000), (48, 2, 20_000, 40_000),
+                                              (31, 10, 400_000, 60_000), (32, 3, 20_000, 40_000), (21, 2, 5_000, 40_000)])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_counting_prefilter_kernels_are_exact(monkeypatch, k, c, genome, reads, canonical):
+    """The count kernels with a counting pre-filter (a count-min row in LDS; only keys whose counter reaches min_count
+    enter the exact table): the two-word one is what a sample's later chunks take when min_count is well above the mean
+    count (BASELINE config 5); forced here from the first chunk on, for one- and two-word keys, at coverages from 20x
+    (few candidates) to 1200x (nearly every key a candidate: the candidates' table overflows and the hash range is
+    split), against the C oracle chunk by chunk."""
+    from oracle import c_oracle
+    monkeypatch.setenv("MK_FORCE_PREFILTER", "1")
+    data = native.synth_reads(genome, 41, reads, 150, 42).tobytes() + b">polyT\n" + b"T" * 400 + b"\n"
+    offs = chunk_offsets(data, 3_000_000)
+    want = {}
+    for a, b in zip(offs[:-1], offs[1:]):
+        if canonical:
+            raw = cpu_ref.count_text(data[a:b], k, 1)
+            part = _fold_filter(raw, c)
+        else:
+            part = c_oracle.count_dict(data[a:b], k, c)
+        for key, n in part.items():
+            want[key] = want.get(key, 0) + n
+    with native.Counter(k, native.ALPHABET_NT2, canonical=canonical) as ctx:
+        for a, b in zip(offs[:-1], offs[1:]):
+            ctx.count_chunk(memoryview(data)[a:b], c)
+        got = ctx.to_dict()
+    assert got == want
