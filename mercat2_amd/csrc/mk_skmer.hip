@@ -914,6 +914,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #define SKP_CNT 16384
 #define SKP_SLOTS 2048
 #define SKP_MAX_PROBE 64
+#define SKP_QCAP 128  // candidates a wave can hold: < 64 left over + one slot x 64 lanes
 
 __device__ __forceinline__ void skp_insert(u64* tkey, unsigned* tcnt, unsigned* ovf, u64 key, unsigned h) {
   unsigned slot = h >> (32 - 11);  // SKP_SLOTS = 2^11
@@ -943,6 +944,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
   __shared__ unsigned cnt32[SKP_CNT];
   __shared__ __attribute__((aligned(16))) u64 tkey[SKP_SLOTS];
   __shared__ unsigned tcnt[SKP_SLOTS];
+  __shared__ __attribute__((aligned(16))) u64 cq[SKC_WAVES][SKP_QCAP];  // candidates, one stack per wave (positions from ballots)
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
   __shared__ unsigned s_abort;
@@ -958,13 +960,42 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
   const int lane = threadIdx.x & 63;
   const unsigned need = min_count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)min_count;
   u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
+  // as in mk_sk_count_k: the next bucket's bounds and its first records are loaded while this one is swept, and a
+  // bucket's first SKC_PRE x 1024 records (nearly always all of them) stay in registers from P to Q
+  unsigned bn = blockIdx.x;
+  u64 lo_n = 0, hi_n = 0, ks_n = 0, ke_n = 0;
+  ulonglong2 pre[SKC_PRE];
+#pragma unroll
+  for (int h = 0; h < SKC_PRE; ++h) pre[h] = make_ulonglong2(0, 0);
+  if (bn < p1) {
+    lo_n = start[bn];
+    hi_n = cursor[bn];
+    ks_n = kstart[bn];
+    ke_n = kstart[bn + 1];
+#pragma unroll
+    for (int h = 0; h < SKC_PRE; ++h) {
+      const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+      if (j < hi_n - lo_n) pre[h] = part[lo_n + j];
+    }
+  }
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
-    const u64 lo = start[b], n = cursor[b] - lo;
-    u64* __restrict__ my_keys = out_keys + kstart[b];
-    u64* __restrict__ my_cnts = out_cnts + kstart[b];
-    const u64 region = kstart[b + 1] - kstart[b];
+    const u64 lo = lo_n, n = hi_n - lo_n;
+    u64* __restrict__ my_keys = out_keys + ks_n;
+    u64* __restrict__ my_cnts = out_cnts + ks_n;
+    const u64 region = ke_n - ks_n;
+    ulonglong2 first[SKC_PRE];
+#pragma unroll
+    for (int h = 0; h < SKC_PRE; ++h) first[h] = pre[h];
+    bn = b + gridDim.x;
+    if (bn < p1) {
+      lo_n = start[bn];
+      hi_n = cursor[bn];
+      ks_n = kstart[bn];
+      ke_n = kstart[bn + 1];
+    }
     unsigned emitted = 0;
     bool counted = false;
+    bool fetched = false;  // the next bucket's records are in pre[]
     records_total += n;
     if (n >> 27) {  // 2^27 records x 31 k-mers would overflow the 32-bit LDS counters
       ++nerr;
@@ -976,64 +1007,136 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
         const unsigned sel_shift = 32 - s;
         unsigned* const ovf = &s_overflow[par];
         u64 win_pass = 0, side_pass = 0;
-        // ---- P
-        for (u64 jb = 0; jb < n; jb += SKC_THREADS) {
-          const u64 j = jb + threadIdx.x;
-          const ulonglong2 rec = j < n ? src[j] : make_ulonglong2(0, 0);
-          const int nk = (int)(rec.y & 63);
-          win_pass += counted ? 0 : (u64)nk;
-          u64 x = rec.x, y = rec.y;
-          u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
+        // ---- P: eight fire-and-forget LDS adds per record, nothing waits for an answer.  The hashes (and which slots
+        //      are live) of the records that stay in registers are kept for Q: that pass then costs a read and a compare
+        //      per key, and the key itself is rebuilt only for the rare candidate
+        unsigned hs[SKC_PRE][SKC_B], lives[SKC_PRE];
+        for (u64 rb2 = 0; rb2 < n; rb2 += SKC_PRE * SKC_THREADS) {
 #pragma unroll
-          for (int u = 0; u < SKC_B; ++u) {
-            const u64 fw = x >> kshift;
-            const u64 key = (CANON && rcv < fw) ? rcv : fw;
-            x = (x << 2) | (y >> 62);
-            y <<= 2;
-            if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
-            const unsigned h = skc_hash(key);
-            bool on = u < nk && (!s || (h >> sel_shift) == idx);
-            if (K32 && key == MK_EMPTY) on = false;
-            if (on) atomicAdd(&cnt32[h & (SKP_CNT - 1)], 1u);
+          for (int h = 0; h < SKC_PRE; ++h) {
+            ulonglong2 rec;
+            if (rb2 == 0) rec = first[h];
+            else {
+              const u64 j = rb2 + (u64)h * SKC_THREADS + threadIdx.x;
+              rec = j < n ? src[j] : make_ulonglong2(0, 0);
+            }
+            const int nk = (int)(rec.y & 63);
+            win_pass += counted ? 0 : (u64)nk;
+            u64 x = rec.x, y = rec.y;
+            u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
+            unsigned live = 0;
+#pragma unroll
+            for (int u = 0; u < SKC_B; ++u) {
+              const u64 fw = x >> kshift;
+              const u64 key = (CANON && rcv < fw) ? rcv : fw;
+              x = (x << 2) | (y >> 62);
+              y <<= 2;
+              if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
+              const unsigned hv = skc_hash(key);
+              bool on = u < nk && (!s || (hv >> sel_shift) == idx);
+              if (K32 && on && key == MK_EMPTY) {
+                side_pass += counted ? 0 : 1;
+                on = false;
+              }
+              if (on) atomicAdd(&cnt32[hv & (SKP_CNT - 1)], 1u);
+              live |= on ? (1u << u) : 0u;
+              if (rb2 == 0) hs[h][u] = hv;
+            }
+            if (rb2 == 0) lives[h] = live;
           }
         }
         __syncthreads();
-        // ---- Q
-        for (u64 jb = 0; jb < n; jb += SKC_THREADS) {
-          const u64 j = jb + threadIdx.x;
-          const ulonglong2 rec = j < n ? src[j] : make_ulonglong2(0, 0);
-          const int nk = (int)(rec.y & 63);
-          u64 x = rec.x, y = rec.y;
-          u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
-          u64 kk[SKC_B];
-          unsigned hh[SKC_B];
-          unsigned cand = 0;
+        // ---- Q: eight independent LDS reads per record; the rare candidate goes onto the wave's stack, and the wave
+        //      inserts 64 of them at a time with every lane busy (one by one in the lane that found them, the inserts'
+        //      LDS round trips ran one after the other: that alone made the kernel slower than the exact one)
+        u64* const myq = cq[threadIdx.x >> 6];
+        unsigned qcount = 0;
+        for (u64 rb2 = 0; rb2 < n; rb2 += SKC_PRE * SKC_THREADS) {
 #pragma unroll
-          for (int u = 0; u < SKC_B; ++u) {
-            const u64 fw = x >> kshift;
-            kk[u] = (CANON && rcv < fw) ? rcv : fw;
-            x = (x << 2) | (y >> 62);
-            y <<= 2;
-            if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
-            hh[u] = skc_hash(kk[u]);
-            bool on = u < nk && (!s || (hh[u] >> sel_shift) == idx);
-            if (K32 && on && kk[u] == MK_EMPTY) {
-              side_pass += counted ? 0 : 1;
-              on = false;
+          for (int h = 0; h < SKC_PRE; ++h) {
+            ulonglong2 rec;
+            if (rb2 == 0) rec = first[h];
+            else {
+              const u64 j = rb2 + (u64)h * SKC_THREADS + threadIdx.x;
+              rec = j < n ? src[j] : make_ulonglong2(0, 0);
             }
-            const unsigned cv = on ? cnt32[hh[u] & (SKP_CNT - 1)] : 0u;
-            cand |= (cv >= need && cv) ? (1u << u) : 0u;
+            unsigned hh[SKC_B], cv[SKC_B];
+            unsigned live = 0;
+            if (rb2 == 0) {
+              live = lives[h];
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u) hh[u] = hs[h][u];
+            } else {
+              const int nk = (int)(rec.y & 63);
+              u64 x = rec.x, y = rec.y;
+              u64 rcv = CANON ? mk_revcomp2(x >> kshift, k) : 0ull;
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u) {
+                const u64 fw = x >> kshift;
+                const u64 key = (CANON && rcv < fw) ? rcv : fw;
+                x = (x << 2) | (y >> 62);
+                y <<= 2;
+                if (CANON) rcv = (rcv >> 2) | ((((x >> kshift) & 3ull) ^ 3ull) << (2 * k - 2));
+                hh[u] = skc_hash(key);
+                bool on = u < nk && (!s || (hh[u] >> sel_shift) == idx);
+                if (K32 && key == MK_EMPTY) on = false;
+                live |= on ? (1u << u) : 0u;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < SKC_B; ++u) cv[u] = ((live >> u) & 1u) ? cnt32[hh[u] & (SKP_CNT - 1)] : 0u;
+            unsigned cand = 0;
+#pragma unroll
+            for (int u = 0; u < SKC_B; ++u) cand |= (cv[u] >= need && cv[u]) ? (1u << u) : 0u;
+            if (__any(cand != 0)) {
+#pragma unroll
+              for (int u = 0; u < SKC_B; ++u) {
+                const bool f = (cand >> u) & 1u;
+                const u64 m = __ballot(f);
+                if (m) {
+                  if (f) {  // window u of the record: its 2k bits start 2u bits into (x : y)
+                    const u64 sx = u ? ((rec.x << (2 * u)) | (rec.y >> (64 - 2 * u))) : rec.x;
+                    myq[qcount + skc_lane_rank(m)] = mk_canon2(sx >> kshift, k, CANON);
+                  }
+                  qcount += (unsigned)__popcll(m);
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  if (qcount >= 64) {
+                    qcount -= 64;
+                    const u64 key = myq[qcount + lane];
+                    skp_insert(tkey, tcnt, ovf, key, skc_hash(key) * 0x9E3779B1u);
+                  }
+                }
+              }
+            }
           }
-          if (cand) {
-#pragma unroll 1
-            for (int u = 0; u < SKC_B; ++u)
-              if ((cand >> u) & 1u) skp_insert(tkey, tcnt, ovf, kk[u], hh[u] * 0x9E3779B1u);
+        }
+        if (qcount) {  // (< 64 left)
+          if ((unsigned)lane < qcount) {
+            const u64 key = myq[lane];
+            skp_insert(tkey, tcnt, ovf, key, skc_hash(key) * 0x9E3779B1u);
           }
+          qcount = 0;
         }
         __syncthreads();  // A
         if (threadIdx.x == 0) cursor[b] = lo;
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
+        // the bucket's last pass? then the next bucket's records start loading now
+        if (!over && !fetched) {
+          int s2 = s;
+          unsigned i2 = idx;
+          while (s2 > 0 && (i2 & 1u)) { i2 >>= 1; --s2; }
+          if (s2 == 0) {
+            fetched = true;
+            if (bn < p1) {
+#pragma unroll
+              for (int h = 0; h < SKC_PRE; ++h) {
+                const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+                pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
+              }
+            }
+          }
+        }
         {
           unsigned occ = 0;
 #pragma unroll
@@ -1094,6 +1197,13 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
           if (s == 0) break;
           ++idx;
         }
+      }
+    }
+    if (!fetched && bn < p1) {  // (an empty or refused bucket: nothing was prefetched by a last pass)
+#pragma unroll
+      for (int h = 0; h < SKC_PRE; ++h) {
+        const u64 j = (u64)h * SKC_THREADS + threadIdx.x;
+        pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
       }
     }
     if (threadIdx.x == 0) nsurv[b] = emitted;

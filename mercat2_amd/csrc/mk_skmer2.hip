@@ -632,6 +632,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
   __shared__ unsigned cnt32[SK2P_CNT];
   __shared__ __attribute__((aligned(16))) ulonglong2 tkey[SK2P_SLOTS];
   __shared__ unsigned tcnt[SK2P_SLOTS];
+  __shared__ __attribute__((aligned(16))) ulonglong2 cq[SK2C_WAVES][SK2C_QCAP];  // candidates, one stack per wave
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
   __shared__ unsigned s_abort;
@@ -687,7 +688,10 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
           }
         }
         __syncthreads();  // P done: the counters are final
-        // ---- Q: the candidates into the exact table
+        // ---- Q: the candidates into the exact table -- via the wave's stack (positions from ballots), 64 at a time with
+        //      every lane busy: inserted one by one in the lane that found them, their LDS round trips run one after the other
+        ulonglong2* const myq = cq[threadIdx.x >> 6];
+        unsigned qcount = 0;
         for (u64 jb = 0; jb < n; jb += SK2C_THREADS) {
           const u64 j = jb + threadIdx.x;
           Sk2Rec rec;
@@ -712,11 +716,30 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
           }
 #pragma unroll
           for (int u = 0; u < SK2_NKMAX; ++u) cand |= (cv[u] >= need && cv[u]) ? (1u << u) : 0u;
-          if (cand) {  // (rare: one lane in a hundred at -c 10)
-#pragma unroll 1
-            for (int u = 0; u < SK2_NKMAX; ++u)
-              if ((cand >> u) & 1u) sk2p_insert(tkey, tcnt, ovf, khi[u], klo[u], sk2c_hash(khi[u], klo[u]));
+          if (__any(cand != 0)) {
+#pragma unroll
+            for (int u = 0; u < SK2_NKMAX; ++u) {
+              const bool f = (cand >> u) & 1u;
+              const u64 m = __ballot(f);
+              if (m) {
+                if (f) myq[qcount + sk2c_lane_rank(m)] = make_ulonglong2(khi[u], klo[u]);
+                qcount += (unsigned)__popcll(m);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                if (qcount >= 64) {
+                  qcount -= 64;
+                  const ulonglong2 key = myq[qcount + lane];
+                  sk2p_insert(tkey, tcnt, ovf, key.x, key.y, sk2c_hash(key.x, key.y));
+                }
+              }
+            }
           }
+        }
+        if (qcount) {  // (< 64 left)
+          if ((unsigned)lane < qcount) {
+            const ulonglong2 key = myq[lane];
+            sk2p_insert(tkey, tcnt, ovf, key.x, key.y, sk2c_hash(key.x, key.y));
+          }
+          qcount = 0;
         }
         __syncthreads();  // A: every insert of the pass is in the table
         if (threadIdx.x == 0) cursor[b] = lo_r;  // back to the region's start: the next chunk may inherit the regions
