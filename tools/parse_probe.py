@@ -10,7 +10,8 @@ from mercat2_amd import native
 chunks = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 text = native.synth_reads(10_000_000, 1, 660_000, 150, 2)
 buf = torch.from_numpy(text).cuda()
-with native.Counter(31, native.ALPHABET_NT2) as ctx:
+import os
+with native.Counter(31, native.ALPHABET_NT2, canonical=bool(os.environ.get('MK_PROBE_CANON'))) as ctx:
     for rep in range(2):
         ctx.reset()
         ctx.set_profiling(rep == 1)
