@@ -501,7 +501,7 @@ def main():
         stage_ms = (st["ms_count"] + st["ms_part"]) / launches
         stage_bytes = alg_bytes + st["symbols"] * 0.25
         stage_achieved = stage_bytes / launches / (stage_ms * 1e-3) / 1e9 if stage_ms > 0 else 0.0
-        kernel_name = {"hash64": "mk_sk_count_k" if 18 <= k <= 32 else "mk_part_count_k", "dense": "mk_count_dense_k",
+        kernel_name = {"hash64": "mk_sk_count_k" if 12 <= k <= 32 else "mk_part_count_k", "dense": "mk_count_dense_k",
                        "byref": "mk_count_byref_k", "hash128": "mk_sk2_count_k"}.get(st["mode_name"], "?")
         if os.environ.get("MK_NO_PARTITION"):
             kernel_name = "mk_count_hash64_k"

@@ -177,6 +177,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
   c->use_superkmer = getenv("MK_NO_SUPERKMER") ? 0 : 1;
   c->use_superkmer2 = getenv("MK_NO_SUPERKMER2") ? 0 : 1;
+  if (const char* e = getenv("MK_SK_MIN_K")) { const int v = atoi(e); if (v >= 12 && v <= 33) c->sk_min_k = v; }
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {
     g_err = msg;
@@ -529,7 +530,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_launch_clean_pre(c, (uint8_t*)c->raw.p, n)) != MK_OK) return rc;
   }
   if (!c->clean_mode && c->use_speculation && c->use_fast_parse && c->alphabet == MK_ALPHABET_NT2 && n && n < 0xFE000000ull &&
-      ((c->mode == MK_MODE_HASH64 && c->use_partition && c->use_superkmer && c->k >= 18 && c->k <= 32) ||
+      ((c->mode == MK_MODE_HASH64 && c->use_partition && c->use_superkmer && c->k >= c->sk_min_k && c->k <= 32) ||
        (c->mode == MK_MODE_HASH128 && c->use_superkmer2))) {
     rc = process_chunk_fast(c, d_raw, n, min_count);
     if (rc != MK_RETRY_GENERAL) return rc;
@@ -624,7 +625,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   if (c->mode == MK_MODE_DENSE) rc = mk_launch_count_dense(c, seq_len);
   else if (partitioned) {
     // (the super-k-mer scatter keeps 32-bit record indices in LDS)
-    const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= 18 && c->k <= 32 && seq_len < 0xFE000000ull;
+    const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= c->sk_min_k && c->k <= 32 && seq_len < 0xFE000000ull;
     rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
   }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);

@@ -22,6 +22,12 @@
 //   bins     u64[4^k | 32^k]  dense histogram (small k)
 // ------------------------------------------------------------------------------------------
 
+// Smallest nucleotide k that takes the super-k-mer partition (mk_skmer.hip): k - 10 minimizer candidates per window.
+// Round 3: 12 (measured on an S2 chunk, Gbases/s against the 8-byte-key partition: k = 12 50 / 42, 14 74 / 47, 16 90 / 46,
+// 17 96 / 21); the environment variable MK_SK_MIN_K (tests / A-B runs) may raise it back to 18, the round-2 threshold.
+#ifndef MK_SK_MIN_K
+#define MK_SK_MIN_K 12
+#endif
 #define MK_SEP 0x0Au
 #define MK_EMPTY 0xFFFFFFFFFFFFFFFFull
 
@@ -151,6 +157,7 @@ struct mk_ctx {
   int use_fast_parse = 1;
   int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)
   int use_superkmer = 1;
+  int sk_min_k = MK_SK_MIN_K;  // nucleotide k from which the super-k-mer partition is used (below: 8-byte-key partition)
   bool part_sampled = false;  // the last super-k-mer partition sized its buckets from a sample
   // bucket regions of the previous chunk kept for the next one (mk_skmer.hip): same size, same min_count, no overflow
   bool part_reuse_ok = false;

@@ -1,4 +1,4 @@
-// mk_skmer.hip -- super-k-mer partitioned counting for nucleotide k-mers, 18 <= k <= 32.
+// mk_skmer.hip -- super-k-mer partitioned counting for nucleotide k-mers, 12 <= k <= 32 (round 2: from 18).
 //
 // Same arithmetic as mk_part.hip (every window +1, keep count >= min_count;
 // lib/mercat2_kmers.py:56-60, 73-76) but the unit that travels through HBM is not the 8-byte
@@ -1384,6 +1384,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     if (c->canonical) launch_wc<W, true>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse); \
     else launch_wc<W, false>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse); \
     break;
+    SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7)
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
     SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
 #undef SK_CASE
