@@ -441,7 +441,10 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   const size_t bad_words = n / 64 + 4;
   if ((rc = mk_buf_reserve(c, c->bad, (bad_words + 2) * 8)) != MK_OK) return rc;
   if ((rc = mk_buf_reserve(c, c->codes, (2 * bad_words + 8) * 8)) != MK_OK) return rc;
-  if ((rc = mk_launch_fparse(c, d_al, begin, n, /*fuse_pack_nt=*/true)) != MK_OK) return rc;
+  // (the parsed stream itself is not written: only the by-reference kernel reads it, and that runs only when the chunk
+  // holds characters outside the alphabet -- the chunk is then parsed once more with the stream, below)
+  static const bool always_seq = getenv("MK_ALWAYS_SEQ") != nullptr;
+  if ((rc = mk_launch_fparse(c, d_al, begin, n, /*fuse_pack_nt=*/true, /*write_seq=*/always_seq)) != MK_OK) return rc;
   const bool two = c->mode == MK_MODE_HASH128;
   c->rtab_chunk_slots = 0;
   c->surv_regions = 0;
@@ -458,6 +461,15 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   }
   const size_t seq_len = (size_t)h->seq_len;
   if (h->bad_symbols) {  // windows holding a symbol outside the alphabet: by reference, now
+    if (!always_seq) {
+      // the by-reference kernel reads the parsed stream, which the first parse did not write: parse again (the raw text
+      // is still there), this time for the stream only -- the packed words, the bitmap and the chunk's counters stand
+      // (the second parse adds to the chunk's counters again -- kept bytes >= 0x80 -- so they are set aside and put back)
+      if ((rc = mk_buf_reserve(c, c->ex_tmp, sizeof(MkChunkInfo) + 64)) != MK_OK) return rc;
+      MK_HIP(hipMemcpyAsync(c->ex_tmp.p, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToDevice, c->stream));
+      if ((rc = mk_launch_fparse(c, d_al, begin, n, /*fuse_pack_nt=*/false, /*write_seq=*/true)) != MK_OK) return rc;
+      MK_HIP(hipMemcpyAsync(c->info.p, c->ex_tmp.p, sizeof(MkChunkInfo), hipMemcpyDeviceToDevice, c->stream));
+    }
     const u64 bound = std::min<u64>((u64)seq_len, h->bad_symbols * (u64)c->k);
     c->rtab_chunk_slots = pow2_at_least(2 * (size_t)bound);
     if ((rc = mk_buf_reserve(c, c->rtab_chunk, c->rtab_chunk_slots * sizeof(MkSlot))) != MK_OK) return rc;

@@ -208,7 +208,7 @@ struct mk_ctx {
 // parse: raw[n] -> seq, info (seq_len, symbols, non_ascii)
 int mk_launch_parse(mk_ctx* c, const uint8_t* d_raw, size_t n);
 // fast parse (mk_fparse.hip): same output; sets info.parse_fallback when its assumption fails
-int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, bool fuse_pack_nt);
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, bool fuse_pack_nt, bool write_seq = true);
 // pack: seq -> codes, bad (+ info.bad_symbols)
 int mk_launch_pack(mk_ctx* c, size_t seq_cap);
 // counting

@@ -289,7 +289,7 @@ __global__ __launch_bounds__(1024) void mk_fparse_scan(const FpEntry* __restrict
 __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __restrict__ raw, size_t begin, size_t n, size_t nwaves,
                                                              FpScan* __restrict__ scan, uint8_t* __restrict__ seq,
                                                              MkChunkInfo* __restrict__ info, u64* __restrict__ codes,
-                                                             u64* __restrict__ bad) {
+                                                             u64* __restrict__ bad, int write_seq) {
   // 64 bytes of slack on both sides: the fused pack reads whole 64-symbol words around the ends
   // (+ 256: one dump word per lane for the bytes a lane drops, see the compaction below)
   __shared__ __attribute__((aligned(16))) uint8_t stage[FP_WAVES][64 + FP_WAVE_BYTES + 32 + 64 + 256];
@@ -356,7 +356,10 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   __threadfence_block();
   uint8_t* __restrict__ dst = seq + (sc.off - shift);
   const unsigned end = shift + filled;
-  for (unsigned c = (unsigned)lane * 16; c < end; c += 64 * 16) {
+  // (write_seq == 0: the caller only wants the packed words and the bad bitmap -- the parsed stream is read again by the
+  // by-reference kernel alone, i.e. only when the chunk holds characters outside the alphabet, and then the chunk is
+  // parsed once more with the stream written: 94 MB per 100 MiB chunk of reads less to write)
+  for (unsigned c = (unsigned)lane * 16; write_seq && c < end; c += 64 * 16) {
     if (c >= shift && c + 16 <= end) {
       *reinterpret_cast<uint4*>(dst + c) = *reinterpret_cast<const uint4*>(lds + c);
     } else {
@@ -436,7 +439,8 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
 
 // Returns MK_OK after enqueueing; info->parse_fallback != 0 afterwards means "re-parse with the general kernels".
 // d_raw is 16-byte aligned; the chunk is its bytes [begin, begin + len) (begin < 16).
-int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, bool fuse_pack_nt) {
+int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, bool fuse_pack_nt, bool write_seq) {
+  if (!fuse_pack_nt) write_seq = true;
   const size_t n = begin + len;
   u64* codes = fuse_pack_nt ? (u64*)c->codes.p : nullptr;
   u64* bad = fuse_pack_nt ? (u64*)c->bad.p : nullptr;
@@ -460,7 +464,7 @@ int mk_launch_fparse(mk_ctx* c, const uint8_t* d_raw, size_t begin, size_t len, 
                      2 * bad_words, bad_words);  // (the summary pass clears the packed words and the bad bitmap)
   hipLaunchKernelGGL(mk_fparse_scan, dim3(1), dim3(1024), 0, c->stream, (const FpEntry*)entries, nwaves, scan, info, bad);
   hipLaunchKernelGGL(mk_fparse_emit, dim3(blocks), dim3(FP_THREADS), 0, c->stream, d_raw, begin, n, nwaves, scan,
-                     (uint8_t*)c->seq.p, info, codes, bad);
+                     (uint8_t*)c->seq.p, info, codes, bad, write_seq ? 1 : 0);
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
   return MK_OK;
