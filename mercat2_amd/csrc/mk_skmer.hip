@@ -528,6 +528,17 @@ __device__ __forceinline__ unsigned skc_step(unsigned slot, unsigned d) {
 #else
 #define SKC_JMAP(h) ((u64)(h) * SKC_THREADS + threadIdx.x)
 #endif
+// A bucket's records are read once, front to back: loaded past the L2's replacement order (SKC_NT_LOAD), so that the
+// 243 MB a chunk's count kernel streams do not push the open lines of the OTHER context's scatter out of the L2s.
+__device__ __forceinline__ ulonglong2 skc_ldrec(const ulonglong2* __restrict__ p) {
+#ifdef SKC_NT_LOAD
+  typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+  const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t*>(p));
+  return make_ulonglong2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
 #define SKC_B 8          // k-mers of a record expanded and probed together
 #define SKC_WAVES (SKC_THREADS / 64)
 #ifndef SKC_PUSH
@@ -624,7 +635,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #pragma unroll
     for (int h = 0; h < SKC_PRE; ++h) {
       const u64 j = SKC_JMAP(h);
-      if (j < hi_n - lo_n) pre[h] = part[lo_n + j];
+      if (j < hi_n - lo_n) pre[h] = skc_ldrec(part + lo_n + j);
     }
   }
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
@@ -681,7 +692,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #pragma unroll
             for (int h = 0; h < SKC_PRE; ++h) {
               const u64 j = rb2 + SKC_JMAP(h);
-              recs2[h] = j < n ? src[j] : make_ulonglong2(0, 0);
+              recs2[h] = j < n ? skc_ldrec(src + j) : make_ulonglong2(0, 0);
             }
           }
           STAMP_ADD(tF, t0);
@@ -794,7 +805,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #pragma unroll
           for (int h = 0; h < SKC_PRE; ++h) {
             const u64 j = SKC_JMAP(h);
-            pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
+            pre[h] = (j < hi_n - lo_n) ? skc_ldrec(part + lo_n + j) : make_ulonglong2(0, 0);
           }
         }
         // ---- emit (when complete) into the bucket's own region, and clear.  The sweep reads the COUNTS only
@@ -871,7 +882,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #pragma unroll
         for (int h = 0; h < SKC_PRE; ++h) {
           const u64 j = SKC_JMAP(h);
-          pre[h] = (j < hi_n - lo_n) ? part[lo_n + j] : make_ulonglong2(0, 0);
+          pre[h] = (j < hi_n - lo_n) ? skc_ldrec(part + lo_n + j) : make_ulonglong2(0, 0);
         }
       }
     }
