@@ -460,17 +460,17 @@ def main():
     if ngpu == 1 and rank == 0 and default_run and not args.no_configs:
         configs = {}
 
-        def short_run(name, kk, canon, reads, genome, gseed, rseed, steps, parts_in=None):
+        def short_run(name, kk, canon, reads, genome, gseed, rseed, steps, parts_in=None, warm=2):
             e2 = Engine(kk, canon, genome, 0)
             try:
                 p2, nch, tot, _ = (parts_in, nchunks, total_bases, 0) if parts_in is not None else load_sample("weak", reads, genome, gseed, rseed, 0)
-                d2, rows2, _ = timed(e2, e2.make_step(p2), steps, 2, True)  # (two warm-up steps: the running tables grow to their size in the first)
+                d2, rows2, _ = timed(e2, e2.make_step(p2), steps, warm, True)  # (warm-up steps: the running tables grow to their size in the first ones)
                 s2 = sum_stats(e2.all)
                 two = s2["mode_name"] == "hash128"
                 bpw = 24 if two else 16
                 ms_l = s2["ms_count"] / max(1, s2["n_count"])
                 ach = (s2["windows"] - s2["exotic_windows"]) * bpw / max(1, s2["n_count"]) / (ms_l * 1e-3) / 1e9 if ms_l > 0 else 0.0
-                configs[name] = {"value": tot * steps / d2, "unit": "bases/s", "ms_per_step": d2 / steps * 1e3, "steps": steps, "warmup": 2,
+                configs[name] = {"value": tot * steps / d2, "unit": "bases/s", "ms_per_step": d2 / steps * 1e3, "steps": steps, "warmup": warm,
                                  "rows": rows2, "chunks": nch, "k": kk, "reads": reads, "genome": genome, "canonical": canon,
                                  "mode": s2["mode_name"], "count_kernel_ms_per_launch": ms_l, "count_kernel_frac": ach / HBM_PEAK_GBS,
                                  "bytes_per_window": bpw,
@@ -479,7 +479,7 @@ def main():
             finally:
                 e2.close()
 
-        short_run("config3_canonical", K, True, READS, GENOME, GENOME_SEED, READ_SEED, max(3, args.steps // 3), parts_in=parts)
+        short_run("config3_canonical", K, True, READS, GENOME, GENOME_SEED, READ_SEED, max(4, args.steps // 2), parts_in=parts, warm=3)
         if configs["config3_canonical"]["verified_rows"] is False:
             verified = False
         del parts

@@ -172,6 +172,8 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   const long kb = (long)k * c->bits;
   c->mode = (c->bits == 0) ? MK_MODE_BYREF : (kb <= 15 ? MK_MODE_DENSE : (kb <= 64 ? MK_MODE_HASH64 : MK_MODE_BYREF));
   if (alphabet == MK_ALPHABET_NT2 && k >= 33 && k <= 64) c->mode = MK_MODE_HASH128;  // packed by-reference
+  // amino acids, 13 <= k <= 25: 5 k <= 125 bits, the same two-word tables (mk_count_ref128aa_k); MK_NO_AA128 = by bytes, as before round 3
+  if (alphabet == MK_ALPHABET_AA5 && k >= 13 && k <= 25 && !getenv("MK_NO_AA128")) c->mode = MK_MODE_HASH128;
   c->st.mode = c->mode;
   c->use_partition = getenv("MK_NO_PARTITION") ? 0 : 1;
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
@@ -616,7 +618,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_launch_clear_slots(c, (MkSlot*)c->ctab.p, c->ctab_slots)) != MK_OK) return rc;
   }
   // partitioned path: no global chunk table (32-bit record indices in the scatter's LDS: chunks below 4 G symbols)
-  const bool sk2 = c->mode == MK_MODE_HASH128 && c->use_superkmer2 && seq_len < 0xFFFFFF00ull;
+  const bool sk2 = c->mode == MK_MODE_HASH128 && c->alphabet == MK_ALPHABET_NT2 && c->use_superkmer2 && seq_len < 0xFFFFFF00ull;
   if (c->mode == MK_MODE_HASH128 && c->canonical && !sk2) {
     c->err = "canonical counting of 33..64-mers needs the partitioned path (chunk of 4 G symbols or more)";
     return MK_ERR_RANGE;
@@ -929,6 +931,11 @@ static inline void decode_row(const mk_ctx* c, const ExportView& v, size_t i, ui
   if (v.words == 1) { decode_key(c, v.pkeys[i], out); return; }
   const u64 hi = v.pkeys[2 * i], lo = v.pkeys[2 * i + 1];  // left-aligned: base j < 32 in hi, the rest in lo
   const int k = c->k;
+  if (c->alphabet == MK_ALPHABET_AA5) {  // amino acids: the number sum(code_j * 32^(k-1-j)) in (hi, lo)
+    unsigned __int128 x = ((unsigned __int128)hi << 64) | lo;
+    for (int j = k - 1; j >= 0; --j) { out[j] = (uint8_t)('A' + (unsigned)(x & 31)); x >>= 5; }
+    return;
+  }
   for (int j = 0; j < 32; ++j) out[j] = "ACGT"[(hi >> (62 - 2 * j)) & 3];
   for (int j = 32; j < k; ++j) out[j] = "ACGT"[(lo >> (62 - 2 * (j - 32))) & 3];
 }

@@ -251,6 +251,26 @@ __device__ __forceinline__ Key128 key128_at(const u64* __restrict__ codes, u64 p
   return r;
 }
 
+// Amino acids, 13 <= k <= 25: 5 bits per symbol, 12 symbols in bits 63..4 of a packed word.  The key is the NUMBER
+// sum(symbol_i * 32^(k-1-i)) in 128 bits (hi = its upper word): fixed length and codes in ASCII order, so (hi, lo)
+// order is the byte order of the k-mer text.  Three packed words hold any such window (11 + 25 = 36 symbols).
+__device__ __forceinline__ Key128 key128aa_from(u64 c0, u64 c1, u64 c2, int o, int k) {
+  const unsigned __int128 p0 = c0 >> 4, p1 = c1 >> 4, p2 = c2 >> 4;  // 60-bit payloads, first symbol on top
+  const unsigned __int128 top = (p0 << 60) | p1;                      // symbols 0 .. 23 of the three words
+  const int r = 180 - 5 * o - 5 * k;                                  // bits to the right of the window, 0 .. 120
+  unsigned __int128 v = r >= 60 ? (top >> (r - 60)) : ((top << (60 - r)) | (p2 >> r));
+  v &= (((unsigned __int128)1 << (5 * k)) - 1);                       // (5 k <= 125)
+  Key128 key;
+  key.hi = (u64)(v >> 64);
+  key.lo = (u64)v;
+  return key;
+}
+__device__ __forceinline__ Key128 key128aa_at(const u64* __restrict__ codes, u64 pos, int k) {
+  const u64 w = pos / 12;
+  return key128aa_from(codes[w], codes[w + 1], codes[w + 2], (int)(pos - w * 12), k);
+}
+
+template <bool AA>
 __device__ __forceinline__ void insert_ref128(MkSlot* __restrict__ table, u64 mask, const u64* __restrict__ codes,
                                               u64 pos, Key128 key, int k) {
   const u64 h = mk_mix64(key.hi ^ mk_mix64(key.lo + 0x9E3779B97F4A7C15ull));
@@ -267,7 +287,7 @@ __device__ __forceinline__ void insert_ref128(MkSlot* __restrict__ table, u64 ma
       }
     }
     if ((cur & ~REF_POS_MASK) == tag) {
-      const Key128 other = key128_at(codes, cur & REF_POS_MASK, k);
+      const Key128 other = AA ? key128aa_at(codes, cur & REF_POS_MASK, k) : key128_at(codes, cur & REF_POS_MASK, k);
       if (other.hi == key.hi && other.lo == key.lo) {
         atomicAdd(&table[slot].cnt, 1ull);
         return;
@@ -313,9 +333,29 @@ __global__ __launch_bounds__(256) void mk_count_ref128_k(const u64* __restrict__
         key.lo = sh ? ((w1 << sh) | (w2 >> (64 - sh))) : w1;
         if (k < 64) key.lo &= ~0ull << (128 - 2 * k);
         (void)w3;
-        insert_ref128(table, mask, codes, (u64)(p0 + j), key, k);
+        insert_ref128<false>(table, mask, codes, (u64)(p0 + j), key, k);
         ++mine;
       }
+    }
+  }
+  add_windows(info, mine, true);
+}
+
+// The same for amino acids (13 <= k <= 25): one thread per packed word = 12 window starts.
+__global__ __launch_bounds__(256) void mk_count_ref128aa_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                           MkChunkInfo* __restrict__ info, MkSlot* __restrict__ table,
+                                                           u64 mask, int k) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t p0 = t * 12;
+  unsigned mine = 0;
+  if (p0 < info->seq_len) {
+    const u64 c0 = codes[t], c1 = codes[t + 1], c2 = codes[t + 2];
+    const u64 kmask = (1ull << k) - 1;  // (k <= 25)
+#pragma unroll 1
+    for (int j = 0; j < 12; ++j) {
+      if ((bad_window(bad, p0 + j) & kmask) != 0) continue;  // (a separator, a character outside 'A'..'Z', or past the end)
+      insert_ref128<true>(table, mask, codes, (u64)(p0 + j), key128aa_from(c0, c1, c2, j, k), k);
+      ++mine;
     }
   }
   add_windows(info, mine, true);
@@ -324,6 +364,16 @@ __global__ __launch_bounds__(256) void mk_count_ref128_k(const u64* __restrict__
 int mk_launch_count_ref128(mk_ctx* c, size_t seq_len) {
   if (seq_len == 0) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  if (c->alphabet == MK_ALPHABET_AA5) {
+    const size_t words = (seq_len + 11) / 12;
+    mk_prof_begin(c, MK_K_COUNT);
+    hipLaunchKernelGGL(mk_count_ref128aa_k, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (MkSlot*)c->rtab_chunk.p,
+                       (u64)(c->rtab_chunk_slots - 1), c->k);
+    mk_prof_end(c);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+  }
   const size_t threads = (seq_len + 31) / 32;
   mk_prof_begin(c, MK_K_COUNT);
   hipLaunchKernelGGL(mk_count_ref128_k, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, c->stream,

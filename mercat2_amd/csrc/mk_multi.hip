@@ -427,7 +427,8 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   u64 bounds[MK_MAX_OWNERS];
   for (auto& b : bounds) b = ~0ull;
   if (m > 1 && packed) {
-    const int key_bits = c0->mode == MK_MODE_HASH128 ? 64 : c0->bits * c0->k;
+    // (first word of a two-word key: nucleotides fill it -- left-aligned; an amino-acid key is a number of 5 k bits)
+    const int key_bits = c0->mode == MK_MODE_HASH128 ? (c0->alphabet == MK_ALPHABET_AA5 ? std::max(1, 5 * c0->k - 64) : 64) : c0->bits * c0->k;
     if ((rc = mk_owner_bounds(key_bits, m, (uint64_t*)bounds)) != MK_OK) return rc;
     if ((flags & MK_MERGE_BALANCED) && (c0->mode == MK_MODE_HASH64 || c0->mode == MK_MODE_HASH128)) {
       size_t total = 0;

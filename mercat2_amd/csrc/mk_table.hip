@@ -391,14 +391,23 @@ __device__ __forceinline__ bool upsert_ref(MkSlot* __restrict__ run, u64 mask, u
 __global__ void mk_accumulate_ref_k(const MkSlot* __restrict__ from, size_t slots, u64 min_count,
                                     const uint8_t* __restrict__ seq, int k, MkSlot* __restrict__ run, u64 run_mask,
                                     uint8_t* __restrict__ arena, u64 arena_base, u64* __restrict__ new_rows,
-                                    MkSlot128* __restrict__ run128, u64 run128_mask, u64* __restrict__ new_rows128) {
+                                    MkSlot128* __restrict__ run128, u64 run128_mask, u64* __restrict__ new_rows128, int aa) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
     ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
     if (s.x != MK_EMPTY && s.y >= min_count && s.y != 0) {
       const uint8_t* str = seq + (s.x & REF_POS_MASK);
       bool packed = run128 != nullptr;
       u64 hi = 0, lo = 0;
-      if (packed) {
+      if (packed && aa) {  // amino acids: the key is the number sum(code_j * 32^(k-1-j)), code = letter - 'A' (mk_count.hip)
+        unsigned __int128 v = 0;
+        for (int j = 0; j < k && packed; ++j) {
+          const unsigned ch = str[j];
+          if (ch < 'A' || ch > 'Z') packed = false;
+          else v = (v << 5) | (unsigned __int128)(ch - 'A');
+        }
+        hi = (u64)(v >> 64);
+        lo = (u64)v;
+      } else if (packed) {
         for (int j = 0; j < k && packed; ++j) {
           const unsigned ch = str[j];
           const unsigned code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
@@ -560,7 +569,7 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count) {
                        c->k, (MkSlot*)c->run_ref.p, (u64)(c->run_ref_slots - 1), (uint8_t*)c->arena.p,
                        (u64)c->run_ref_rows, &info->new_rows_ref,
                        c->mode == MK_MODE_HASH128 ? (MkSlot128*)c->run128.p : (MkSlot128*)nullptr,
-                       (u64)(c->run128_slots ? c->run128_slots - 1 : 0), &info->new_rows);
+                       (u64)(c->run128_slots ? c->run128_slots - 1 : 0), &info->new_rows, c->alphabet == MK_ALPHABET_AA5 ? 1 : 0);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());

@@ -142,7 +142,8 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
         extras = _all_extras(int(ex_c.size), world, dev if not staged else torch.device("cpu"), group)
     else:
         packed = mode in ("hash64", "hash128")  # byref keeps every row as text
-        bits = 64 if words == 2 else key_bits
+        # (first word of a two-word key: nucleotides fill it; an amino-acid key is a number of 5 k bits)
+        bits = (max(1, 5 * ctx.k - 64) if ctx.alphabet == 1 else 64) if words == 2 else key_bits
         bounds = (balanced_bounds(ctx, bits, world, group, dev) if (balanced and packed) else range_bounds(bits, world))
         cap = ctx.rows() + 1
         rows = torch.empty((cap, words + 1), dtype=torch.int64, device=dev)

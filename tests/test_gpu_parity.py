@@ -938,3 +938,54 @@ def test_counting_prefilter_kernels_are_exact(monkeypatch, k, c, genome, reads, 
             ctx.count_chunk(memoryview(data)[a:b], c)
         got = ctx.to_dict()
     assert got == want
+
+
+@pytest.mark.parametrize("k", [13, 14, 20, 24, 25])
+def test_amino_acid_two_word_keys(k):
+    """Protein k-mers of 13..25 residues are packed two-word keys (5 k <= 125 bits: mk_count_ref128aa_k), not text:
+    same table as the oracle -- rows in byte order, residues outside 'A'..'Z' and lower case kept as text rows --
+    also when the chunks are dealt to three contexts and merged by key range (owner bounds over the 5 k - 64 bits of
+    the key's first word)."""
+    rng = np.random.default_rng(k)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    base = ["".join(aa[x] for x in rng.integers(0, 20, 400)) for _ in range(40)]
+    recs = []
+    for i in range(1500):
+        s = base[int(rng.integers(0, 40))]
+        a = int(rng.integers(0, 300))
+        piece = s[a:a + int(rng.integers(k - 3, 100))]
+        if i % 17 == 0:
+            piece = piece[:5] + "X*" + piece[5:] + "BZJOU"
+        if i % 29 == 0:
+            piece = piece[:9] + piece[9:].lower()
+        recs.append(">p%d # 1\n%s*\n" % (i, "\n".join(piece[j:j + 60] for j in range(0, len(piece), 60))))
+    data = "".join(recs).encode()
+    for c in (1, 3):
+        want = cpu_ref.count_text(data, k, c)
+        with native.Counter(k, native.ALPHABET_AA5) as ctx:
+            ctx.count_chunk(data, c)
+            assert ctx.stats()["mode_name"] == "hash128" and ctx.words_per_key() == 2
+            kmers, counts = ctx.export()
+            assert ctx.to_dict() == want
+        keys = [bytes(r) for r in kmers]
+        assert keys == sorted(keys)
+    offs = chunk_offsets(data, 30_000)
+    spans = list(zip(offs[:-1], offs[1:]))
+    want = {}
+    for a, b in spans:
+        for key, n in cpu_ref.count_text(data[a:b], k, 2).items():
+            want[key] = want.get(key, 0) + n
+    ctxs = [native.Counter(k, native.ALPHABET_AA5) for _ in range(3)]
+    try:
+        for i, (a, b) in enumerate(spans):
+            ctxs[i % 3].count_chunk(data[a:b], 2)
+        native.merge_devices(ctxs, native.MERGE_RANGES)
+        km, cn = native.export_multi(ctxs)
+        flat = km.tobytes().decode()
+        assert dict(zip((flat[i:i + k] for i in range(0, len(flat), k)), cn.tolist())) == want
+    finally:
+        for x in ctxs:
+            x.close()
+    with native.Counter(26, native.ALPHABET_AA5) as ctx:  # 130 bits: text rows, as before
+        ctx.count_chunk(data, 1)
+        assert ctx.stats()["mode_name"] == "byref" and ctx.to_dict() == cpu_ref.count_text(data, 26, 1)
