@@ -179,6 +179,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->use_fast_parse = getenv("MK_NO_FAST_PARSE") ? 0 : 1;
   c->use_superkmer = getenv("MK_NO_SUPERKMER") ? 0 : 1;
   c->use_superkmer2 = getenv("MK_NO_SUPERKMER2") ? 0 : 1;
+  c->run_bucket_major = (getenv("MK_BUCKET_MAJOR") && alphabet == MK_ALPHABET_NT2 && c->mode == MK_MODE_HASH64 && k >= 12 && k <= 32) ? 1 : 0;
   if (const char* e = getenv("MK_SK_MIN_K")) { const int v = atoi(e); if (v >= 12 && v <= 33) c->sk_min_k = v; }
   int rc = MK_OK;
   auto fail = [&](int code, const std::string& msg) {

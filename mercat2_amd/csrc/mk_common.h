@@ -157,6 +157,7 @@ struct mk_ctx {
   int use_fast_parse = 1;
   int canonical = 0;      // opt-in: count min(kmer, revcomp) (nt only)
   int use_superkmer = 1;
+  int run_bucket_major = 0;  // one-word running table addressed bucket-major (mk_table.hip: RunAddr; experiment, MK_BUCKET_MAJOR=1)
   int sk_min_k = MK_SK_MIN_K;  // nucleotide k from which the super-k-mer partition is used (below: 8-byte-key partition)
   bool part_sampled = false;  // the last super-k-mer partition sized its buckets from a sample
   // bucket regions of the previous chunk kept for the next one (mk_skmer.hip): same size, same min_count, no overflow

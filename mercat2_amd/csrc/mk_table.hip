@@ -6,6 +6,7 @@
 // before the merge -- there is no post-merge filter in the reference (SURVEY.md trap T2).
 #include "mk_common.h"
 #include "mk_device.h"
+#include "mk_skmer_dev.h"
 
 typedef unsigned long long u64;
 #define REF_POS_BITS 40
@@ -56,9 +57,48 @@ int mk_launch_count_survivors(mk_ctx* c, uint64_t min_count) {
 }
 
 // ------------------------------------------------------------------- running table: hash64
+// Where a key's probe sequence starts.  Plain: a mixing hash of the key.  BUCKET-MAJOR (nucleotide keys of the
+// super-k-mer path, tables of at least 2^13 slots; experiment switch MK_BUCKET_MAJOR): the table is 2^13 slices, one per
+// minimizer bucket, and a key starts in the slice of ITS bucket -- the bucket its windows were filed under when they
+// were counted, recomputed here from the key alone (the smallest 11-mer of the key in the partition's order) -- at a
+// hashed offset.  The survivors a chunk's count kernel emits for one bucket then all land in one slice of the table
+// (a few tens of KB) instead of anywhere in it.  Probing is linear over the whole table either way: a full slice spills
+// into the next.
+struct RunAddr {
+  u64 mask;      // slots - 1 (a power of two)
+  int k;         // > 0: bucket-major addressing for k-mers of this length
+  int canon;
+};
+__device__ __forceinline__ unsigned run_bucket13(u64 key, int k, bool canon) {
+  unsigned best = ~0u;
+  for (int q = 0; q + SK_M <= k; ++q) {
+    const unsigned mm = (unsigned)(key >> (2 * (k - SK_M - q))) & SK_MASK;
+    const unsigned o = (sk_order_raw(sk_canon_mmer(mm, canon)) << 10) | (unsigned)q;  // (as sk_analyse: leftmost on ties)
+    best = o < best ? o : best;
+  }
+  const int q = (int)(best & 63u);
+  const unsigned mm = (unsigned)(key >> (2 * (k - SK_M - q))) & SK_MASK;
+  return sk_bucket(sk_canon_mmer(mm, canon), 13);
+}
+__device__ __forceinline__ u64 run_home(const RunAddr& a, u64 key) {
+  const u64 h = mk_mix64(key);
+  if (a.k <= 0 || a.mask < 8191) return h & a.mask;
+  const u64 per = (a.mask + 1) >> 13;  // slots per slice
+  return (u64)run_bucket13(key, a.k, a.canon != 0) * per + (h & (per - 1));
+}
+
+static RunAddr run_addr(const mk_ctx* c, size_t slots) {
+  RunAddr a;
+  a.mask = (u64)(slots - 1);
+  a.k = c->run_bucket_major ? c->k : 0;
+  a.canon = c->canonical;
+  return a;
+}
+
 // Returns true when the key was new to the table.
-__device__ __forceinline__ bool upsert64(MkSlot* __restrict__ table, u64 mask, u64 key, u64 add) {
-  u64 slot = mk_mix64(key) & mask;
+__device__ __forceinline__ bool upsert64(MkSlot* __restrict__ table, const RunAddr& addr, u64 key, u64 add) {
+  const u64 mask = addr.mask;
+  u64 slot = run_home(addr, key);
   for (;;) {
     u64 cur = table[slot].key;
     bool fresh = false;
@@ -75,7 +115,7 @@ __device__ __forceinline__ bool upsert64(MkSlot* __restrict__ table, u64 mask, u
 }
 
 __global__ void mk_accumulate64_k(const MkSlot* __restrict__ from, size_t slots, u64 min_count, MkSlot* __restrict__ run,
-                                  u64 run_mask, u64* __restrict__ new_rows) {
+                                  RunAddr run_mask, u64* __restrict__ new_rows) {
   u64 fresh = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
     ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
@@ -88,7 +128,7 @@ __global__ void mk_accumulate64_k(const MkSlot* __restrict__ from, size_t slots,
 // the rows -- rows received from several peers are a concatenation of sorted segments -- its count goes
 // to *side (the context keeps that one key beside the table).
 __global__ void mk_import_pairs_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
-                                  MkSlot* __restrict__ run, u64 run_mask, u64* __restrict__ new_rows, u64* __restrict__ side) {
+                                  MkSlot* __restrict__ run, RunAddr run_mask, u64* __restrict__ new_rows, u64* __restrict__ side) {
   u64 fresh = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
     const u64 key = keys[i], cnt = cnts[i];
@@ -104,8 +144,9 @@ __global__ void mk_import_pairs_k(const u64* __restrict__ keys, const u64* __res
 // races (two new keys may want it: compare-and-swap); the count of a slot that holds the key is this lane's alone and
 // is read and written with plain accesses -- one 16-byte load and one 8-byte store per key instead of a load and an
 // atomic add that the L2 has to serialise (canonical S2: 2.2 M survivors per chunk; the merge was a third of the step).
-__device__ __forceinline__ bool upsert64_distinct(MkSlot* __restrict__ table, u64 mask, u64 key, u64 add) {
-  u64 slot = mk_mix64(key) & mask;
+__device__ __forceinline__ bool upsert64_distinct(MkSlot* __restrict__ table, const RunAddr& addr, u64 key, u64 add) {
+  const u64 mask = addr.mask;
+  u64 slot = run_home(addr, key);
   for (;;) {
     const ulonglong2 s = *reinterpret_cast<const ulonglong2*>(&table[slot]);
     u64 cur = s.x;
@@ -130,7 +171,7 @@ __device__ __forceinline__ bool upsert64_distinct(MkSlot* __restrict__ table, u6
 
 // Survivors laid out per bucket: bucket b holds nsurv[b] pairs from kstart[b] on. One wave per bucket.
 __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, const u64* __restrict__ kstart,
-                                    const u64* __restrict__ nsurv, size_t p1, MkSlot* __restrict__ run, u64 run_mask,
+                                    const u64* __restrict__ nsurv, size_t p1, MkSlot* __restrict__ run, RunAddr run_mask,
                                     u64* __restrict__ new_rows) {
   u64 fresh = 0;
   const int lane = threadIdx.x & 63;
@@ -155,7 +196,7 @@ int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* 
   const unsigned cap = survivors > 64 * p1 ? 4096u : 512u;
   hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, cap)), dim3(256), 0, c->stream, (const u64*)d_keys,
                      (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
-                     (u64)(c->run_slots - 1), &info->new_rows);
+                     run_addr(c, c->run_slots), &info->new_rows);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
@@ -474,11 +515,12 @@ __global__ void mk_rehash_ref_k(const MkSlot* __restrict__ from, size_t slots, M
   }
 }
 
-__global__ void mk_rehash64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, u64 to_mask) {
+__global__ void mk_rehash64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, RunAddr to_addr) {
+  const u64 to_mask = to_addr.mask;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
     ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
     if (s.x == MK_EMPTY) continue;
-    u64 slot = mk_mix64(s.x) & to_mask;
+    u64 slot = run_home(to_addr, s.x);
     for (;;) {
       if (atomicCAS(&to[slot].key, MK_EMPTY, s.x) == MK_EMPTY) {
         to[slot].cnt = s.y;
@@ -491,14 +533,15 @@ __global__ void mk_rehash64_k(const MkSlot* __restrict__ from, size_t slots, MkS
 
 // Rebuild keeping only rows with count >= min_count (the post-merge filter of a single-chunk sample split
 // over several ranks); *kept counts them.
-__global__ void mk_refilter64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, u64 to_mask, u64 min_count,
+__global__ void mk_refilter64_k(const MkSlot* __restrict__ from, size_t slots, MkSlot* __restrict__ to, RunAddr to_addr, u64 min_count,
                                 u64* __restrict__ kept) {
+  const u64 to_mask = to_addr.mask;
   u64 mine = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < slots; i += (size_t)gridDim.x * blockDim.x) {
     ulonglong2 s = reinterpret_cast<const ulonglong2*>(from)[i];
     if (s.x == MK_EMPTY || s.y < min_count || s.y == 0) continue;
     ++mine;
-    u64 slot = mk_mix64(s.x) & to_mask;
+    u64 slot = run_home(to_addr, s.x);
     for (;;) {
       if (atomicCAS(&to[slot].key, MK_EMPTY, s.x) == MK_EMPTY) {
         to[slot].cnt = s.y;
@@ -533,7 +576,7 @@ __global__ void mk_refilter_dense_k(u64* __restrict__ bins, size_t nbins, u64 mi
     if (bins[i] < min_count) bins[i] = 0;
 }
 int mk_launch_refilter64(mk_ctx* c, const MkSlot* from, MkSlot* to, size_t slots, uint64_t min_count, uint64_t* d_kept) {
-  hipLaunchKernelGGL(mk_refilter64_k, dim3(grid_for(slots, 256, 8192)), dim3(256), 0, c->stream, from, slots, to, (u64)(slots - 1),
+  hipLaunchKernelGGL(mk_refilter64_k, dim3(grid_for(slots, 256, 8192)), dim3(256), 0, c->stream, from, slots, to, run_addr(c, slots),
                      (u64)min_count, (u64*)d_kept);
   MK_HIP(hipGetLastError());
   return MK_OK;
@@ -554,7 +597,7 @@ int mk_launch_merge_table64(mk_ctx* c, const MkSlot* from, size_t from_slots) {
   if (!from_slots) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   hipLaunchKernelGGL(mk_accumulate64_k, dim3(grid_for(from_slots, 256, 2048)), dim3(256), 0, c->stream, from, from_slots, (u64)0,
-                     (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows);
+                     (MkSlot*)c->run.p, run_addr(c, c->run_slots), &info->new_rows);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
@@ -562,7 +605,7 @@ int mk_launch_merge_table64(mk_ctx* c, const MkSlot* from, size_t from_slots) {
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots) {
   if (!from_slots) return MK_OK;
   hipLaunchKernelGGL(mk_rehash64_k, dim3(grid_for(from_slots, 256, 8192)), dim3(256), 0, c->stream, from, from_slots, to,
-                     (u64)(to_slots - 1));
+                     run_addr(c, to_slots));
   MK_HIP(hipGetLastError());
   return MK_OK;
 }
@@ -586,7 +629,7 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count) {
   } else if (c->mode == MK_MODE_HASH64 && c->ctab_slots && c->h_info->survivors) {
     hipLaunchKernelGGL(mk_accumulate64_k, dim3(grid_for(c->ctab_slots, 256, 8192)), dim3(256), 0, c->stream,
                        (const MkSlot*)c->ctab.p, c->ctab_slots, (u64)min_count, (MkSlot*)c->run.p,
-                       (u64)(c->run_slots - 1), &info->new_rows);
+                       run_addr(c, c->run_slots), &info->new_rows);
   }
   if (c->rtab_chunk_slots && c->h_info->survivors_ref) {
     hipLaunchKernelGGL(mk_accumulate_ref_k, dim3(grid_for(c->rtab_chunk_slots, 256, 8192)), dim3(256), 0, c->stream,
@@ -610,7 +653,7 @@ int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_
                        (const u64*)d_counts, rows, (u64*)c->run.p, nbins);
   } else {
     hipLaunchKernelGGL(mk_import_pairs_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
-                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows, &info->side);
+                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, run_addr(c, c->run_slots), &info->new_rows, &info->side);
   }
   MK_HIP(hipGetLastError());
   return MK_OK;
@@ -618,7 +661,7 @@ int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_
 
 // Interleaved rows {key, count} / {hi, lo, count} / {bin, count}: the layout rows travel in between GPUs
 // (mk_multi.hip, mercat2_amd/dist.py), so that a row's words move side by side and are read with one access.
-__global__ void mk_import_rows64_k(const ulonglong2* __restrict__ rows2, size_t rows, MkSlot* __restrict__ run, u64 run_mask,
+__global__ void mk_import_rows64_k(const ulonglong2* __restrict__ rows2, size_t rows, MkSlot* __restrict__ run, RunAddr run_mask,
                                    u64* __restrict__ new_rows, u64* __restrict__ side) {
   u64 fresh = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
@@ -653,7 +696,7 @@ int mk_launch_import_rows(mk_ctx* c, const uint64_t* d_rows, size_t rows) {
                        (u64*)c->run.p, (size_t)1 << (c->bits * c->k));
   } else if (c->mode == MK_MODE_HASH64) {
     hipLaunchKernelGGL(mk_import_rows64_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const ulonglong2*)d_rows,
-                       rows, (MkSlot*)c->run.p, (u64)(c->run_slots - 1), &info->new_rows, &info->side);
+                       rows, (MkSlot*)c->run.p, run_addr(c, c->run_slots), &info->new_rows, &info->side);
   } else if (c->mode == MK_MODE_HASH128) {
     hipLaunchKernelGGL(mk_import_rows128_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_rows, rows,
                        (MkSlot128*)c->run128.p, (u64)(c->run128_slots - 1), &info->new_rows);
