@@ -302,6 +302,160 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
   if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
 
+// The same scatter with two sub-tiles per tile (half the cursor atomics per record) and the walks FLATTENED through an
+// LDS queue, as mk_sk_scatterq_k does for one-word keys (mk_skmer.hip, where the case is made): a lane only LISTS its
+// runs -- one 32-bit item {lane, first window, windows, minimizer position, later the bucket} per record -- and the wave
+// works its queue off 64 items at a time with every lane busy.  A record needs FOUR packed words here; thread t holds
+// words t and t + 1 (its 32 bases and the 32 after them), so its words 2 and 3 are the SECOND words of its two right
+// neighbours: every sub-tile parks its threads' word pairs in LDS plus the pairs of the two threads to its right.  Forward-strand keys only: the canonical analysis files a window under a VALUE, not
+// under a position in its first 32 bases, and keeps the kernel above.
+#define SK2Q_SUBT 2
+#define SK2Q_CAP 512
+#define SK2Q_WAVES (SK2_SCAT_THREADS / 64)
+#define SK2Q_WALKED 0xFFFFFFFFu
+#define SK2_NOFIT 0xFF000000u
+__global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+                                                                      MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
+                                                                      u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
+                                                                      int p1_log2, int k, size_t ntiles, unsigned qcap) {
+  __shared__ unsigned lh[SK2_MAX_P1];  // counts, then base + rank (record indices stay below SK2_NOFIT: the launcher checks)
+  __shared__ ulonglong2 pk_w[SK2Q_SUBT][SK2_SCAT_THREADS + 2];
+  __shared__ unsigned queue[SK2Q_SUBT][SK2Q_WAVES][SK2Q_CAP];  // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
+  __shared__ unsigned s_abort;
+  if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
+  __syncthreads();
+  if (s_abort) return;
+  unsigned spilled = 0;
+  constexpr int NB = SK2_MAX_P1 / SK2_SCAT_THREADS;
+  const unsigned p1 = 1u << p1_log2;
+  const size_t seq_len = info->seq_len;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+  __syncthreads();
+  for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    unsigned qn[SK2Q_SUBT];
+#pragma unroll
+    for (int st = 0; st < SK2Q_SUBT; ++st) {
+      const size_t t = (tile * SK2Q_SUBT + st) * SK2_SCAT_THREADS + threadIdx.x;
+      const size_t p0 = t * SK2_R;
+      Sk2Runs runs;
+      runs.valid = 0;
+      runs.starts = 0;
+      runs.pos[0] = runs.pos[1] = runs.pos[2] = runs.pos[3] = 0;
+      u64 w0 = 0, w1 = 0;
+      if (p0 < seq_len) {
+        w0 = codes[t];
+        w1 = codes[t + 1];
+        runs = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
+      }
+      pk_w[st][threadIdx.x] = make_ulonglong2(w0, w1);
+      if (threadIdx.x == SK2_SCAT_THREADS - 1) {  // the word pairs of the two threads to the right of the sub-tile's last one
+        pk_w[st][SK2_SCAT_THREADS] = p0 < seq_len ? make_ulonglong2(codes[t + 1], codes[t + 2]) : make_ulonglong2(0, 0);
+        pk_w[st][SK2_SCAT_THREADS + 1] = p0 < seq_len ? make_ulonglong2(codes[t + 2], codes[t + 3]) : make_ulonglong2(0, 0);
+      }
+      const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, SK2_NKMAX);
+      const unsigned cnt = __popc(s2);
+      unsigned inc = cnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(inc, d);
+        if (lane >= d) inc += up;
+      }
+      const unsigned total = __shfl(inc, 63);
+      unsigned* const myq = queue[st][wv];
+      if (total <= qcap) {
+        unsigned todo = s2, at = inc - cnt;
+        while (todo) {
+          const int j = __ffs(todo) - 1;
+          todo &= todo - 1;
+          const unsigned stop = (s2 | ~runs.valid) & ~((2u << j) - 1);
+          const int nk = (stop ? (__ffs(stop) - 1) : SK2_R) - j;
+          const u64 pw = j < 10 ? runs.pos[0] : (j < 20 ? runs.pos[1] : (j < 30 ? runs.pos[2] : runs.pos[3]));
+          const unsigned best = (unsigned)(pw >> (6 * (j % 10))) & 63u;
+          myq[at++] = (unsigned)lane | ((unsigned)j << 6) | ((unsigned)nk << 11) | (best << 16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (unsigned base = 0; base < total; base += 64) {
+          const unsigned i = base + lane;
+          if (i < total) {
+            const unsigned it = myq[i];
+            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
+            const unsigned b = sk2_bucket(sk_mmer(w.x, w.y, (int)(it >> 16)), p1_log2);
+            atomicAdd(&lh[b], 1u);
+            myq[i] = (it & 0xFFFFu) | (b << 16);
+          }
+        }
+        qn[st] = total;
+      } else {
+        if (p0 < seq_len) sk2_walk(runs, w0, w1, [&](int, int, unsigned mm) { atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u); });
+        qn[st] = SK2Q_WALKED;
+      }
+    }
+    __syncthreads();
+    {
+      unsigned v[NB];
+      u64 r[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        v[i] = b < p1 ? lh[b] : 0u;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
+        if (b < p1) {
+          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+          spilled |= fits ? 0u : 1u;
+          lh[b] = fits ? (unsigned)r[i] : SK2_NOFIT;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < SK2Q_SUBT; ++st) {
+      if (qn[st] != SK2Q_WALKED) {
+        const unsigned total = qn[st];
+        const unsigned* const myq = queue[st][wv];
+        for (unsigned base = 0; base < total; base += 64) {
+          const unsigned i = base + lane;
+          if (i < total) {
+            const unsigned it = myq[i];
+            const unsigned at = atomicAdd(&lh[it >> 16], 1u);  // base + rank
+            const unsigned src = (wv << 6) | (it & 63u);
+            const ulonglong2 wa = pk_w[st][src];
+            const Sk2Rec rec = sk2_make_record(wa.x, wa.y, pk_w[st][src + 1].y, pk_w[st][src + 2].y, (int)((it >> 6) & 31u),
+                                               (int)((it >> 11) & 31u), k);
+            if (at < SK2_NOFIT) part[(size_t)at] = rec;
+          }
+        }
+      } else {
+        const size_t t = (tile * SK2Q_SUBT + st) * SK2_SCAT_THREADS + threadIdx.x;
+        const size_t p0 = t * SK2_R;
+        if (p0 < seq_len) {
+          const ulonglong2 wa = pk_w[st][threadIdx.x];
+          const u64 w2 = pk_w[st][threadIdx.x + 1].y, w3 = pk_w[st][threadIdx.x + 2].y;
+          const Sk2Runs runs = sk2_analyse(wa.x, wa.y, sk2_valid32(bad, p0, k));
+          sk2_walk(runs, wa.x, wa.y, [&](int jstart, int nk, unsigned mm) {
+            const unsigned at = atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u);
+            if (at < SK2_NOFIT) part[(size_t)at] = sk2_make_record(wa.x, wa.y, w2, w3, jstart, nk, k);
+          });
+        }
+      }
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+  }
+  if (spilled) atomicOr(&info->part_overflow, 4ull);
+}
+
 // ------------------------------------------------------------------------------------- count
 // Slot hash of a two-word key: six full-rate 24-bit multiplies over its 24-bit pieces (a 32-bit multiply issues at a
 // quarter of the rate; see skc_hash in mk_skmer.hip).  Bits 31.. pick the slot, bits 15..0 the sub-range.
@@ -887,9 +1041,17 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   if (c->canonical)
     hipLaunchKernelGGL(mk_sk2_scatter_k<true>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
-  else
+  else if (getenv("MK_SCATTER_WALK") || part_cap >= SK2_NOFIT)
     hipLaunchKernelGGL(mk_sk2_scatter_k<false>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
+  else {
+    unsigned qcap = SK2Q_CAP;
+    if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && v < SK2Q_CAP) qcap = (unsigned)v; }
+    const size_t qtiles = div_up(threads, (size_t)SK2_SCAT_THREADS * SK2Q_SUBT);
+    hipLaunchKernelGGL(mk_sk2_scatterq_k, dim3((unsigned)(qtiles < 4096 ? qtiles : 4096)), dim3(SK2_SCAT_THREADS), 0, c->stream,
+                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p,
+                       p1_log2, k, qtiles, qcap);
+  }
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
   {

@@ -799,7 +799,8 @@ def test_equal_chunks_inherit_bucket_regions(monkeypatch):
 
 
 @pytest.mark.parametrize("qcap", ["0", "300", None])
-def test_scatter_queue_and_walk_agree(monkeypatch, qcap):
+@pytest.mark.parametrize("walk", [False, True])
+def test_scatter_queue_and_walk_agree(monkeypatch, qcap, walk):
     """The scatter lists a wave's runs in an LDS queue and works them off with every lane busy; a wave whose runs do
     not fit the queue walks them lane by lane instead (and analyses the sub-tile again for the second pass).
     MK_SKQ_CAP lowers the queue's capacity: 0 walks every wave, 300 about half of them (k = 21: ~6 runs per
@@ -807,9 +808,15 @@ def test_scatter_queue_and_walk_agree(monkeypatch, qcap):
     from oracle import c_oracle
     if qcap is not None:
         monkeypatch.setenv("MK_SKQ_CAP", qcap)
+    if walk:
+        if qcap is not None:
+            pytest.skip("the walking kernels have no queue")
+        monkeypatch.setenv("MK_SCATTER_WALK", "1")
     data = native.synth_reads(300_000, 5, 70_000, 150, 6).tobytes()
     low = b">poly\n" + b"A" * 20_000 + b"\n>n\n" + (b"ACGTTGCAAGGCTTAACGGATCCATGCAAGTCCN" * 1500) + b"\n"
-    for k, c, canon in ((21, 2, False), (31, 1, False), (18, 1, False), (32, 2, False), (25, 1, True)):
+    # (two-word keys, 33 <= k <= 64: the same queue form in mk_sk2_scatterq_k, forward-strand keys)
+    for k, c, canon in ((21, 2, False), (31, 1, False), (18, 1, False), (32, 2, False), (25, 1, True), (12, 2, False), (14, 1, True),
+                        (63, 1, False), (33, 2, False), (48, 1, False), (64, 1, False), (63, 1, True)):
         payload = data + low
         want = _fold_filter(c_oracle.count_dict(payload, k, 0), c) if canon else c_oracle.count_dict(payload, k, c)
         with native.Counter(k, native.ALPHABET_NT2, canonical=canon) as ctx:
