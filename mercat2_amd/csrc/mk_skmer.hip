@@ -409,7 +409,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
             const unsigned it = myq[i];
             const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
             const unsigned mm = sk_canon_mmer(sk_mmer(w.x, w.y, (int)(it >> 16)), CANON);
+#ifdef SK_ABL_COARSE  // (timing ablation only: the first level of a two-level partition -- p1 / 64 coarse buckets)
+            const unsigned b = sk_bucket(mm, p1_log2) & ~63u;
+#else
             const unsigned b = sk_bucket(mm, p1_log2);
+#endif
             atomicAdd(&lh[b], 1u);
             myq[i] = (it & 0xFFFFu) | (b << 16);
           }
@@ -439,7 +443,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
       for (int i = 0; i < NB; ++i) {
         const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
         if (b < p1) {
+#ifdef SK_ABL_COARSE
+          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 64 < p1 ? b + 64 : p1];
+#else
           const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+#endif
           spilled |= fits ? 0u : 1u;
           lh[b] = fits ? (unsigned)r[i] : SK_NOFIT;
         }
