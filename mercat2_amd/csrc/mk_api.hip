@@ -490,6 +490,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     rc = two ? mk_launch_count_superkmer2(c, seq_len, min_count, /*exact=*/true) : mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true);
     if (rc) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
+    if (h->part_overflow) { c->err = "partition overflow after the exact pass (internal error: nothing was counted)"; return MK_ERR_STATE; }
   }
   if (h->errors) {
     c->err = "counting kernel reported " + std::to_string(h->errors) + " unrecoverable condition(s) (bucket too large to split)";
@@ -667,6 +668,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
              : mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true);
     if (rc) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
+    if (c->h_info->part_overflow) { c->err = "partition overflow after the exact pass (internal error: nothing was counted)"; return MK_ERR_STATE; }
   }
   if (c->h_info->errors) {
     c->err = "counting kernel reported " + std::to_string(c->h_info->errors) + " unrecoverable condition(s) (bucket too large to split)";

@@ -225,7 +225,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
 // mk_skmer.hip: bucket regions (records and survivors) from an exact or sampled histogram, in one kernel
 bool mk_part_inherit(mk_ctx* c, size_t seq_len, int p1_log2, uint64_t min_count, bool sampled, bool exact);  // mk_skmer.hip
 void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned long long* khist, unsigned long long* start,
-                       unsigned long long* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
+                       unsigned* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
                        unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);

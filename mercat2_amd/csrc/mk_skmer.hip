@@ -159,7 +159,7 @@ __device__ __forceinline__ u64 sk_cap(u64 h, int sample_log2, u64 weight, float 
   return est + (u64)dev + 1 + (sigmas > 0 ? 16 * weight : 0);
 }
 __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ hist, const u64* __restrict__ khist,
-                                                     u64* __restrict__ start, u64* __restrict__ cursor, u64* __restrict__ kstart,
+                                                     u64* __restrict__ start, SkCursor* __restrict__ cursor, u64* __restrict__ kstart,
                                                      MkChunkInfo* __restrict__ info, int p1_log2, int sample_log2, int nkmax,
                                                      u64 div, u64 part_cap, u64 surv_cap, float sigmas) {
   constexpr int PER = SK_MAX_P1 / 1024;  // buckets per thread (p1 <= SK_MAX_P1)
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ his
 template <int W, bool CANON>
 __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                    MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
-                                                                   u64* __restrict__ cursor, ulonglong2* __restrict__ part,
+                                                                   SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                                    int p1_log2, int k, int nkmax, size_t ntiles, int canon) {
   // lh[b]: pass 1 counts the tile's records of bucket b; after the reservation it holds the record index at which
   // the tile's run in that bucket starts (the launcher keeps indices below SK_NOFIT) and pass 2's atomic add hands
@@ -338,35 +338,57 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 // and writes the bucket into the item; pass 2 needs nothing but the item and those words.  Nothing of the analysis
 // lives across the reservation.  A wave whose runs do not fit its queue (SKQ_CAP items per sub-tile: 8 per lane, the
 // mean is below 5) walks that sub-tile the old way and analyses it again in pass 2 -- rare, content-dependent, exact.
+#ifdef MK_STAMP
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
+#define STAMP_ADD(acc, t0) { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; }
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, t0)
+#endif
+#ifdef MK_STAMP
+__device__ u64 skq_dbg[1024 * 8];  // per workgroup: time of wave 0 in each phase of mk_sk_scatterq_k
+#endif
 #ifndef SKQ_CAP
 #define SKQ_CAP 512
 #endif
-#define SKQ_WAVES (SK_SCAT_THREADS / 64)
+#if defined(SK_ABL_COARSE) && !defined(SK_PLAIN_CURSORS)
+#error "SK_ABL_COARSE needs -DSK_PLAIN_CURSORS (the ablation's region ends differ from the ones sk_reserve8k checks)"
+#endif
+#ifndef SKQ_THREADS
+#define SKQ_THREADS 512  // two workgroups per CU (72 KB of LDS each): one's reservations and record stores -- memory-side --
+#endif                   // run under the other's analysis; 1024: one workgroup per CU, a quarter fewer reservations
+#define SKQ_WAVES (SKQ_THREADS / 64)
 #define SKQ_WALKED 0xFFFFFFFFu
 template <int W, bool CANON>
-__global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+__global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                          MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
-                                                         u64* __restrict__ cursor, ulonglong2* __restrict__ part,
+                                                         SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                          int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap) {
   __shared__ unsigned lh[SK_MAX_P1];  // as above: counts, then base + rank
-  __shared__ ulonglong2 pk_w[SK_SCAT_SUBT][SK_SCAT_THREADS];          // every thread's two words
+  // every thread's first word; its second is the next lane's first, and a wave keeps the second word of its last lane
+  // itself (pass 1 runs between wave barriers only: a wave must not read what another wave writes)
+  __shared__ u64 pk_x[SK_SCAT_SUBT][SKQ_WAVES][65];
   __shared__ unsigned queue[SK_SCAT_SUBT][SKQ_WAVES][SKQ_CAP];        // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
   __shared__ unsigned s_abort;
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
   if (s_abort) return;  // the regions do not fit the buffers: nothing may be written
   unsigned spilled = 0;
-  constexpr int NB = SK_MAX_P1 / SK_SCAT_THREADS;
+  constexpr int NB = SK_MAX_P1 / SKQ_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
   __syncthreads();
+  u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, ntile = 0;
+  (void)tA; (void)tB; (void)tC; (void)tD; (void)tE; (void)tF; (void)t0; (void)ntile;
+  STAMP(t0);
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    ntile += 1;
     unsigned qn[SK_SCAT_SUBT];  // items queued per sub-tile (wave-uniform), or SKQ_WALKED
 #pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
-      const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+      const size_t t = (tile * SK_SCAT_SUBT + st) * SKQ_THREADS + threadIdx.x;
       const size_t p0 = t * SK_R;
       SkRuns runs;
       runs.valid = 0;
@@ -377,8 +399,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
         ww0 = codes[t];
         ww1 = codes[t + 1];
         runs = sk_analyse<W>(ww0, ww1, sk_valid32(bad_window(bad, p0), k), CANON);
+      } else if (p0 < seq_len + SK_R) {
+        ww0 = codes[t];  // (the thread before this one is the last with windows: this is its second word)
       }
-      pk_w[st][threadIdx.x] = make_ulonglong2(ww0, ww1);
+      pk_x[st][wv][lane] = ww0;
+      if (lane == 63) pk_x[st][wv][64] = ww1;
       const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, nkmax);
       const unsigned cnt = __popc(s2);
       unsigned inc = cnt;  // inclusive scan over the wave
@@ -407,8 +432,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
           const unsigned i = base + lane;
           if (i < total) {
             const unsigned it = myq[i];
-            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
-            const unsigned mm = sk_canon_mmer(sk_mmer(w.x, w.y, (int)(it >> 16)), CANON);
+            const u64* const wp = &pk_x[st][wv][it & 63u];
+            const unsigned mm = sk_canon_mmer(sk_mmer(wp[0], wp[1], (int)(it >> 16)), CANON);
 #ifdef SK_ABL_COARSE  // (timing ablation only: the first level of a two-level partition -- p1 / 64 coarse buckets)
             const unsigned b = sk_bucket(mm, p1_log2) & ~63u;
 #else
@@ -425,35 +450,39 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
         qn[st] = SKQ_WALKED;
       }
     }
+    STAMP_ADD(tA, t0);
     __syncthreads();
-    {
-      unsigned v[NB];
-      u64 r[NB];
+    STAMP_ADD(tB, t0);
+#ifndef SK_PLAIN_CURSORS
+    if (p1 == SK_MAX_P1) {  // (8192 buckets, 8 per thread: all reservations in flight together, mk_skmer_dev.h)
+      static_assert(NB % 8 == 0, "sk_reserve8");
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        v[i] = b < p1 ? lh[b] : 0u;
+      for (int h = 0; h < NB; h += 8) {  // (512 threads: buckets 0..4095, then 4096..8191)
+        unsigned v[8], at[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = lh[threadIdx.x + (h + i) * SKQ_THREADS];
+        spilled |= sk_reserve8<SKQ_THREADS>(v, cursor + h * SKQ_THREADS, start + h * SKQ_THREADS, SK_NOFIT, at);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lh[threadIdx.x + (h + i) * SKQ_THREADS] = at[i];
       }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK_SCAT_THREADS;
-        if (b < p1) {
-#ifdef SK_ABL_COARSE
-          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 64 < p1 ? b + 64 : p1];
-#else
-          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
+    } else
 #endif
-          spilled |= fits ? 0u : 1u;
-          lh[b] = fits ? (unsigned)r[i] : SK_NOFIT;
-        }
+    {  // (fewer buckets than the most -- small chunks: a plain loop, one bucket at a time)
+      for (unsigned b = threadIdx.x; b < p1; b += SKQ_THREADS) {
+        const unsigned v = lh[b];
+        const u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
+#ifdef SK_ABL_COARSE
+        const bool fits = v == 0 || r + v <= start[b + 64 < p1 ? b + 64 : p1];
+#else
+        const bool fits = v == 0 || r + v <= start[b + 1];
+#endif
+        spilled |= fits ? 0u : 1u;
+        lh[b] = fits ? (unsigned)r : SK_NOFIT;
       }
     }
+    STAMP_ADD(tC, t0);
     __syncthreads();
+    STAMP_ADD(tD, t0);
 #pragma unroll
     for (int st = 0; st < SK_SCAT_SUBT; ++st) {
       if (qn[st] != SKQ_WALKED) {
@@ -464,8 +493,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
           if (i < total) {
             const unsigned it = myq[i];
             const unsigned at = atomicAdd(&lh[it >> 16], 1u);  // base + rank
-            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
-            ulonglong2 rec = sk_make_record(w.x, w.y, (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
+            const u64* const wp = &pk_x[st][wv][it & 63u];
+            ulonglong2 rec = sk_make_record(wp[0], wp[1], (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
             asm volatile("" : "+v"(rec.x), "+v"(rec.y));  // (built while the LDS answers)
 #ifdef SK_NT_STORE  // (timing experiment: streaming stores -- no L2 allocation for the record lines)
             typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
@@ -476,10 +505,10 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
           }
         }
       } else {
-        const size_t t = (tile * SK_SCAT_SUBT + st) * SK_SCAT_THREADS + threadIdx.x;
+        const size_t t = (tile * SK_SCAT_SUBT + st) * SKQ_THREADS + threadIdx.x;
         const size_t p0 = t * SK_R;
         if (p0 < seq_len) {
-          const ulonglong2 w = pk_w[st][threadIdx.x];
+          const ulonglong2 w = make_ulonglong2(pk_x[st][wv][lane], pk_x[st][wv][lane + 1]);
           const SkRuns runs = sk_analyse<W>(w.x, w.y, sk_valid32(bad_window(bad, p0), k), CANON);
           sk_walk(runs, w.x, w.y, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
             const unsigned at = atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u);
@@ -488,10 +517,15 @@ __global__ __launch_bounds__(1024) void mk_sk_scatterq_k(const u64* __restrict__
         }
       }
     }
+    STAMP_ADD(tE, t0);
     __syncthreads();
     for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
     __syncthreads();
+    STAMP_ADD(tF, t0);
   }
+#ifdef MK_STAMP
+  if (threadIdx.x == 0 && blockIdx.x < 1024) { u64* d = skq_dbg + (size_t)blockIdx.x * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = tF; d[6] = ntile; }
+#endif
   if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
 
@@ -586,13 +620,6 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
   }
 }
 
-#ifdef MK_STAMP
-#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
-#define STAMP_ADD(acc, t0) { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; }
-#else
-#define STAMP(var)
-#define STAMP_ADD(acc, t0)
-#endif
 
 // Persistent: gridDim.x workgroups (one per CU) walk the buckets b = blockIdx.x, +gridDim.x, ...
 // The next bucket's bounds and its first two record batches are loaded while the current
@@ -600,7 +627,7 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
 // K32: k == 32, the only k whose keys can equal the free-slot mark (32 x 'T'): that key is counted aside.
 template <bool CANON, bool K32>
 __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
-                                                             u64* __restrict__ cursor,
+                                                             SkCursor* __restrict__ cursor,
                                                              const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
@@ -957,7 +984,7 @@ __device__ __forceinline__ void skp_insert(u64* tkey, unsigned* tcnt, unsigned* 
 
 template <bool CANON, bool K32>
 __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* __restrict__ part, const u64* __restrict__ start,
-                                                              u64* __restrict__ cursor, const u64* __restrict__ kstart,
+                                                              SkCursor* __restrict__ cursor, const u64* __restrict__ kstart,
                                                               u64* __restrict__ nsurv, MkChunkInfo* __restrict__ info, u64 min_count,
                                                               u64* __restrict__ out_keys, u64* __restrict__ out_cnts, int k, unsigned p1) {
   __shared__ unsigned cnt32[SKP_CNT];
@@ -1248,7 +1275,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
 // longest first (classes = 8: every length its own class; classes = 2: five windows or more first) -- what a scatter
 // that files records by length class would hand the count kernel.  One workgroup per bucket, counting sort through LDS.
 __global__ __launch_bounds__(256) void mk_sk_expsort_k(ulonglong2* __restrict__ part, const u64* __restrict__ start,
-                                                       const u64* __restrict__ cursor, unsigned p1, int classes) {
+                                                       const SkCursor* __restrict__ cursor, unsigned p1, int classes) {
   __shared__ ulonglong2 buf[6144];
   __shared__ unsigned cnt[64], base[64];
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
@@ -1279,7 +1306,7 @@ __global__ __launch_bounds__(256) void mk_sk_expsort_k(ulonglong2* __restrict__ 
 
 // ------------------------------------------------------------------------------ launcher
 
-void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start, u64* cursor, u64* kstart, int p1_log2,
+void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start, SkCursor* cursor, u64* kstart, int p1_log2,
                        int sample_log2, int nkmax, u64 surv_div, u64 part_cap, u64 surv_cap, float sigmas) {
   hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, khist, start, cursor, kstart,
                      (MkChunkInfo*)c->info.p, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
@@ -1287,13 +1314,14 @@ void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start,
 
 template <int W, bool CANON>
 static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
-                     u64* hist, u64* start, u64* cursor, u64* khist, u64* kstart, bool reuse) {
+                     u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   float sigmas = 6.0f;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
   if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = (float)atof(e);
   const size_t threads = div_up(seq_len, SK_R);
   const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
+  const size_t qtiles = div_up(threads, (size_t)SKQ_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
   const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
   if (!reuse) {  // (reuse: the regions of the previous chunk stand as they are, cursors back at their starts)
@@ -1311,9 +1339,21 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
                        (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
   else
-    hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
+    hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON>), dim3((unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID)), dim3(SKQ_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
-                       (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, qcap);
+                       (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+#ifdef MK_STAMP
+  if (!walked) {
+    (void)hipStreamSynchronize(c->stream);
+    const unsigned g = (unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID);
+    std::vector<u64> h(8 * 1024);
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(skq_dbg), h.size() * 8);
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (unsigned w = 0; w < g && w < 1024; ++w) for (int q = 0; q < 7; ++q) a[q] += (double)h[w * 8 + q] / g;
+    fprintf(stderr, "[stamp scatterq] per WG (wave 0): analyse+list+pass1=%.0f barrier1=%.0f cursors=%.0f barrier2=%.0f pass2=%.0f barrier3+clear=%.0f tiles=%.2f grid=%u\n",
+            a[0], a[1], a[2], a[3], a[4], a[5], a[6], g);
+  }
+#endif
 }
 
 #ifdef MK_STAMP
@@ -1391,8 +1431,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
   u64* hist = (u64*)c->part_meta.p;
   u64* start = hist + p1;
-  u64* cursor = start + p1 + 1;
-  u64* khist = cursor + p1;
+  SkCursor* cursor = (SkCursor*)(start + p1 + 1);  // (packed 32-bit, in the space of p1 64-bit words)
+  u64* khist = start + p1 + 1 + p1;
   u64* kstart = khist + p1;
   u64* nsurv = kstart + p1 + 1 + p1;  // (the p1 words in between: a cursor array the 8-byte-key path uses)
   if (!reuse) MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
@@ -1414,7 +1454,7 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   mk_prof_end(c);
 #ifdef SK_EXP_SORT
   if (const char* e = getenv("MK_EXP_SORT"))
-    hipLaunchKernelGGL(mk_sk_expsort_k, dim3(2048), dim3(256), 0, c->stream, (ulonglong2*)c->part.p, (const u64*)start, (const u64*)cursor,
+    hipLaunchKernelGGL(mk_sk_expsort_k, dim3(2048), dim3(256), 0, c->stream, (ulonglong2*)c->part.p, (const u64*)start, (const SkCursor*)cursor,
                        (unsigned)p1, atoi(e));
 #endif
   mk_prof_begin(c, MK_K_COUNT);

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(SK2_HIST_THREADS) void mk_sk2_hist_k(const u64* __r
 template <bool CANON>
 __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                      MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
-                                                                     u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
+                                                                     SkCursor* __restrict__ cursor, Sk2Rec* __restrict__ part,
                                                                      int p1_log2, int k, size_t ntiles) {
   __shared__ unsigned lh[SK2_MAX_P1];
   __shared__ unsigned gbase[SK2_MAX_P1];  // (record indices stay below 2^32: the caller checks the chunk size)
@@ -258,6 +258,20 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
       }
     }
     __syncthreads();
+#ifndef SK_PLAIN_CURSORS
+    if (p1 == SK2_MAX_P1) {  // (8192 buckets, 8 per thread: all reservations in flight together, mk_skmer_dev.h)
+      static_assert(NB == 8 && SK2_SCAT_THREADS == 1024, "sk_reserve8");
+      unsigned v[NB], at[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) v[i] = lh[threadIdx.x + i * SK2_SCAT_THREADS];
+      spilled |= sk_reserve8<SK2_SCAT_THREADS>(v, cursor, start, ~0u, at);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        gbase[threadIdx.x + i * SK2_SCAT_THREADS] = at[i];
+        lh[threadIdx.x + i * SK2_SCAT_THREADS] = 0;
+      }
+    } else
+#endif
     {
       unsigned v[NB];
       u64 r[NB];
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 #define SK2_NOFIT 0xFF000000u
 __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                       MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
-                                                                      u64* __restrict__ cursor, Sk2Rec* __restrict__ part,
+                                                                      SkCursor* __restrict__ cursor, Sk2Rec* __restrict__ part,
                                                                       int p1_log2, int k, size_t ntiles, unsigned qcap) {
   __shared__ unsigned lh[SK2_MAX_P1];  // counts, then base + rank (record indices stay below SK2_NOFIT: the launcher checks)
   __shared__ ulonglong2 pk_w[SK2Q_SUBT][SK2_SCAT_THREADS + 2];
@@ -394,6 +408,17 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
       }
     }
     __syncthreads();
+#ifndef SK_PLAIN_CURSORS
+    if (p1 == SK2_MAX_P1) {
+      static_assert(NB == 8 && SK2_SCAT_THREADS == 1024, "sk_reserve8");
+      unsigned v[NB], at[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) v[i] = lh[threadIdx.x + i * SK2_SCAT_THREADS];
+      spilled |= sk_reserve8<SK2_SCAT_THREADS>(v, cursor, start, SK2_NOFIT, at);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) lh[threadIdx.x + i * SK2_SCAT_THREADS] = at[i];
+    } else
+#endif
     {
       unsigned v[NB];
       u64 r[NB];
@@ -519,7 +544,7 @@ __device__ __forceinline__ void sk2c_drain(ulonglong2* tkey, unsigned* tcnt, con
 
 template <bool CANON>
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
-                                                               u64* __restrict__ cursor,
+                                                               SkCursor* __restrict__ cursor,
                                                                const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                                MkChunkInfo* __restrict__ info, u64 min_count,
                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
@@ -778,7 +803,7 @@ __device__ __forceinline__ void sk2p_insert(ulonglong2* tkey, unsigned* tcnt, un
 
 template <bool CANON>
 __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __restrict__ part, const u64* __restrict__ start,
-                                                                u64* __restrict__ cursor,
+                                                                SkCursor* __restrict__ cursor,
                                                                 const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                                 MkChunkInfo* __restrict__ info, u64 min_count,
                                                                 u64* __restrict__ out_hi, u64* __restrict__ out_lo,
@@ -1014,8 +1039,8 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   if ((rc = mk_buf_reserve(c, c->surv_cnts, surv_cap * sizeof(u64))) != MK_OK) return rc;
   u64* hist = (u64*)c->part_meta.p;
   u64* start = hist + p1;
-  u64* cursor = start + p1 + 1;
-  u64* khist = cursor + p1;
+  SkCursor* cursor = (SkCursor*)(start + p1 + 1);  // (packed 32-bit, in the space of p1 64-bit words)
+  u64* khist = start + p1 + 1 + p1;
   u64* kstart = khist + p1;
   u64* kcursor = kstart + p1 + 1;
   u64* nsurv = kcursor + p1;

@@ -38,6 +38,63 @@ __device__ __forceinline__ unsigned sk_mmer(u64 w0, u64 w1, int q) {
   return (unsigned)(x >> (64 - 2 * SK_M));
 }
 
+// Bucket cursors are PACKED 32-BIT record indices (a chunk on these paths has fewer than 2^32 - 2^24 records: the
+// callers check): the L2's atomic rate goes by the lines a wave's 64 lanes touch, and 13 M reservations per S2 chunk --
+// 1 610 tiles x 8 192 buckets -- are a third of the scatter (tools/cursor_atomic_probe.hip: 64-bit cursors 88-92 us,
+// 32-bit at an 8-byte stride 79-83, 32-bit packed 44-46, private to an XCD 88, without return 84).
+typedef unsigned SkCursor;
+
+// A tile's reservations, eight per thread: thread t of THREADS reserves count[i] records in bucket t + THREADS i
+// (i = 0..7; `cursor` and `start` point at the first of these 8 x THREADS buckets, all of which exist) and learns whether
+// the run fits the bucket's region.  The 8 cursor adds (lanes without records
+// masked off) and the 8 region ends are in flight together, one wait.  Written out: under the scatter kernels' register
+// pressure the compiler spilled the 8 addresses and put a full wait in front of every atomic and every load (in-kernel
+// stamps, mk_sk_scatterq_k: 34 K of a tile's 104 K cycles went into this block).  Base pointers are uniform (scalar
+// registers), one 32-bit offset per thread.  base[i] = the run's first record, or `nofit`; returns 1 when a run does
+// not fit.
+// (s_nop 4 in front of every access: the base pointers may have just come out of a v_readlane -- the compiler parks scalar
+// registers in vector lanes here -- and a vector-memory instruction must not read a scalar register within 5 cycles of a
+// vector instruction writing it; inside inline assembly the compiler does not insert those wait states itself.)
+#ifndef SK_PLAIN_CURSORS
+template <int THREADS>
+__device__ __forceinline__ unsigned sk_reserve8(const unsigned (&count)[8], SkCursor* cursor, const u64* start, unsigned nofit,
+                                                unsigned (&base)[8]) {
+  unsigned r[8];
+  u64 lim[8];
+  const unsigned voff4 = threadIdx.x * 4u, voff8 = threadIdx.x * 8u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    u64 saved;  // exec while the lanes without records sit the add out
+    r[i] = 0;
+    asm volatile(
+        "v_cmp_ne_u32 vcc, 0, %3\n\t"
+        "s_and_saveexec_b64 %1, vcc\n\t"
+        "s_nop 4\n\t"
+        "global_atomic_add %0, %2, %3, %4 sc0\n\t"
+        "s_mov_b64 exec, %1"
+        : "+v"(r[i]), "=&s"(saved)
+        : "v"(voff4), "v"(count[i]), "s"(cursor + i * THREADS)
+        : "memory", "vcc");
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2 offset:8" : "=&v"(lim[i]) : "v"(voff8), "s"(start + i * THREADS) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(lim[0]),
+                 "+v"(lim[1]), "+v"(lim[2]), "+v"(lim[3]), "+v"(lim[4]), "+v"(lim[5]), "+v"(lim[6]), "+v"(lim[7])
+               :
+               : "memory");
+  unsigned spilled = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bool fits = count[i] == 0 || (u64)r[i] + count[i] <= lim[i];
+    spilled |= fits ? 0u : 1u;
+    base[i] = fits ? r[i] : nofit;
+  }
+  return spilled;
+}
+#endif
+
 // Result of analysing a thread's 32 windows: which are valid, where runs start, and the 6-bit
 // minimizer position of every window (packed 10 per word).
 // Windows j = 0..31 whose k bases are all clean, from the 64 bad bits that start at the thread's
@@ -58,7 +115,7 @@ struct SkRuns {
 };
 
 // W = k - SK_M + 1 minimizer candidates per window (compile time: the sliding minimum is a
-// doubling network with static indices).
+// network of minima with static indices).
 template <int W>
 __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, unsigned valid, bool canon) {
   constexpr int NQ = SK_R + W - 1;  // candidate positions 0 .. NQ-1
@@ -75,15 +132,36 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, unsigned valid, boo
       // (canonical mode: one bit reversal per candidate.  Rolling the reverse complement along -- the base that enters
       // on the right enters it, complemented, on the left -- was measured slower, 361-371 against 335 us per S2 chunk:
       // it chains the 52 candidates of a thread one behind the other, the reversals are independent of each other)
-      ord[q] = (sk_order_raw(sk_canon_mmer(mm, canon)) << 10) | (unsigned)q;  // (the hash's low 22 bits on top, bits 6..9 zero)
+      // (the hash's low 22 bits on top, bits 6..9 zero.  The register constraint keeps the shift out of the multiply:
+      // folded, the multiplier no longer fits 24 bits and the multiply-add becomes a quarter-rate v_mul_lo_u32 + add)
+      unsigned h = sk_order_raw(sk_canon_mmer(mm, canon));
+#ifndef SK_MIN_DOUBLING
+      asm("" : "+v"(h));
+#endif
+      ord[q] = (h << 10) | (unsigned)q;
     }
   }
-  constexpr int P = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;
+#ifdef SK_MIN_DOUBLING  // (A/B: the round-2 form -- two-input minima, widths 1, 2, 4, 8, 16 -- and the folded multiply)
+  constexpr int WB = (W >= 16) ? 16 : (W >= 8) ? 8 : (W >= 4) ? 4 : (W >= 2) ? 2 : 1;
 #pragma unroll
-  for (int step = 1; step < P; step <<= 1) {
+  for (int step = 1; step < WB; step <<= 1) {
 #pragma unroll
     for (int q = 0; q + step < NQ; ++q) ord[q] = min(ord[q], ord[q + step]);
   }
+#else
+  // Sliding minimum over W candidates with three-input minima: the width covered triples (offsets 0, w, 2w) while
+  // 3w <= W; the last step, in the loop below, closes to exactly W (W <= 22: two rounds at most).
+  constexpr int WA = W >= 3 ? 3 : 1, WB = W >= 9 ? 9 : WA;
+  if constexpr (W >= 3) {
+#pragma unroll
+    for (int q = 0; q + 2 < NQ; ++q) ord[q] = min(min(ord[q], ord[q + 1]), ord[q + 2]);
+  }
+  if constexpr (W >= 9) {
+#pragma unroll
+    for (int q = 0; q + 8 < NQ; ++q) ord[q] = min(min(ord[q], ord[q + 3]), ord[q + 6]);
+  }
+  static_assert(W <= 3 * WB, "a third round of minima would be needed");
+#endif
   // static, branch-free: minimizer positions and run starts (first valid window, minimizer
   // moved, or previous window invalid)
   SkRuns r;
@@ -94,7 +172,11 @@ __device__ __forceinline__ SkRuns sk_analyse(u64 w0, u64 w1, unsigned valid, boo
 #pragma unroll
   for (int j = 0; j < SK_R; ++j) {
     const bool ok = (valid >> j) & 1u;
-    const unsigned best = min(ord[j], ord[j + W - P]) & 63u;
+    unsigned best;  // ord[q] covers candidates q .. q + WB - 1
+    if constexpr (W == WB) best = ord[j];
+    else if constexpr (W <= 2 * WB) best = min(ord[j], ord[j + W - WB]);
+    else best = min(min(ord[j], ord[j + WB]), ord[j + W - WB]);
+    best &= 63u;
     r.starts |= (ok && best != prev_pos) ? (1u << j) : 0u;
     prev_pos = ok ? best : 64u;
     r.pos[j / 10] |= (u64)best << (6 * (j % 10));
