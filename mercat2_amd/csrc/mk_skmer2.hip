@@ -272,29 +272,15 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
       }
     } else
 #endif
-    {
-      unsigned v[NB];
-      u64 r[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        v[i] = b < p1 ? lh[b] : 0u;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        if (b < p1) {
-          // a run that would cross the end of its bucket's region (sampled sizes only) is not written
-          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
-          spilled |= fits ? 0u : 1u;
-          gbase[b] = fits ? (unsigned)r[i] : ~0u;
-          lh[b] = 0;
-        }
+    {  // (small chunks, fewer buckets: one at a time)
+      for (unsigned b = threadIdx.x; b < p1; b += SK2_SCAT_THREADS) {
+        const unsigned v = lh[b];
+        const u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
+        // a run that would cross the end of its bucket's region (sampled sizes only) is not written
+        const bool fits = v == 0 || r + v <= start[b + 1];
+        spilled |= fits ? 0u : 1u;
+        gbase[b] = fits ? (unsigned)r : ~0u;
+        lh[b] = 0;
       }
     }
     __syncthreads();
@@ -325,22 +311,27 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 // under a position in its first 32 bases, and keeps the kernel above.
 #define SK2Q_SUBT 2
 #define SK2Q_CAP 512
-#define SK2Q_WAVES (SK2_SCAT_THREADS / 64)
+#ifndef SK2Q_THREADS
+#define SK2Q_THREADS 512  // two workgroups per CU, as mk_sk_scatterq_k (72 KB of LDS each)
+#endif
+#define SK2Q_WAVES (SK2Q_THREADS / 64)
 #define SK2Q_WALKED 0xFFFFFFFFu
 #define SK2_NOFIT 0xFF000000u
-__global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
+__global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                       MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                       SkCursor* __restrict__ cursor, Sk2Rec* __restrict__ part,
                                                                       int p1_log2, int k, size_t ntiles, unsigned qcap) {
   __shared__ unsigned lh[SK2_MAX_P1];  // counts, then base + rank (record indices stay below SK2_NOFIT: the launcher checks)
-  __shared__ ulonglong2 pk_w[SK2Q_SUBT][SK2_SCAT_THREADS + 2];
+  // every thread's first word, wave by wave, and the three words after the wave's last lane: a thread's words 1..3 are
+  // the first words of the three threads to its right (pass 1 runs between wave barriers only: a wave reads its own row)
+  __shared__ u64 pk_x[SK2Q_SUBT][SK2Q_WAVES][67];
   __shared__ unsigned queue[SK2Q_SUBT][SK2Q_WAVES][SK2Q_CAP];  // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
   __shared__ unsigned s_abort;
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
   if (s_abort) return;
   unsigned spilled = 0;
-  constexpr int NB = SK2_MAX_P1 / SK2_SCAT_THREADS;
+  constexpr int NB = SK2_MAX_P1 / SK2Q_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -350,7 +341,7 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
     unsigned qn[SK2Q_SUBT];
 #pragma unroll
     for (int st = 0; st < SK2Q_SUBT; ++st) {
-      const size_t t = (tile * SK2Q_SUBT + st) * SK2_SCAT_THREADS + threadIdx.x;
+      const size_t t = (tile * SK2Q_SUBT + st) * SK2Q_THREADS + threadIdx.x;
       const size_t p0 = t * SK2_R;
       Sk2Runs runs;
       runs.valid = 0;
@@ -362,10 +353,11 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
         w1 = codes[t + 1];
         runs = sk2_analyse(w0, w1, sk2_valid32(bad, p0, k));
       }
-      pk_w[st][threadIdx.x] = make_ulonglong2(w0, w1);
-      if (threadIdx.x == SK2_SCAT_THREADS - 1) {  // the word pairs of the two threads to the right of the sub-tile's last one
-        pk_w[st][SK2_SCAT_THREADS] = p0 < seq_len ? make_ulonglong2(codes[t + 1], codes[t + 2]) : make_ulonglong2(0, 0);
-        pk_w[st][SK2_SCAT_THREADS + 1] = p0 < seq_len ? make_ulonglong2(codes[t + 2], codes[t + 3]) : make_ulonglong2(0, 0);
+      pk_x[st][wv][lane] = w0;
+      if (lane == 63) {
+        pk_x[st][wv][64] = w1;
+        pk_x[st][wv][65] = p0 < seq_len ? codes[t + 2] : 0ull;
+        pk_x[st][wv][66] = p0 < seq_len ? codes[t + 3] : 0ull;
       }
       const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, SK2_NKMAX);
       const unsigned cnt = __popc(s2);
@@ -395,8 +387,8 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
           const unsigned i = base + lane;
           if (i < total) {
             const unsigned it = myq[i];
-            const ulonglong2 w = pk_w[st][(wv << 6) | (it & 63u)];
-            const unsigned b = sk2_bucket(sk_mmer(w.x, w.y, (int)(it >> 16)), p1_log2);
+            const u64* const wp = &pk_x[st][wv][it & 63u];
+            const unsigned b = sk2_bucket(sk_mmer(wp[0], wp[1], (int)(it >> 16)), p1_log2);
             atomicAdd(&lh[b], 1u);
             myq[i] = (it & 0xFFFFu) | (b << 16);
           }
@@ -410,36 +402,25 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
     __syncthreads();
 #ifndef SK_PLAIN_CURSORS
     if (p1 == SK2_MAX_P1) {
-      static_assert(NB == 8 && SK2_SCAT_THREADS == 1024, "sk_reserve8");
-      unsigned v[NB], at[NB];
+      static_assert(NB % 8 == 0, "sk_reserve8");
 #pragma unroll
-      for (int i = 0; i < NB; ++i) v[i] = lh[threadIdx.x + i * SK2_SCAT_THREADS];
-      spilled |= sk_reserve8<SK2_SCAT_THREADS>(v, cursor, start, SK2_NOFIT, at);
+      for (int h = 0; h < NB; h += 8) {
+        unsigned v[8], at[8];
 #pragma unroll
-      for (int i = 0; i < NB; ++i) lh[threadIdx.x + i * SK2_SCAT_THREADS] = at[i];
+        for (int i = 0; i < 8; ++i) v[i] = lh[threadIdx.x + (h + i) * SK2Q_THREADS];
+        spilled |= sk_reserve8<SK2Q_THREADS>(v, cursor + h * SK2Q_THREADS, start + h * SK2Q_THREADS, SK2_NOFIT, at);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lh[threadIdx.x + (h + i) * SK2Q_THREADS] = at[i];
+      }
     } else
 #endif
-    {
-      unsigned v[NB];
-      u64 r[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        v[i] = b < p1 ? lh[b] : 0u;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        r[i] = v[i] ? atomicAdd(&cursor[b], (u64)v[i]) : 0ull;
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const unsigned b = threadIdx.x + i * SK2_SCAT_THREADS;
-        if (b < p1) {
-          const bool fits = v[i] == 0 || r[i] + v[i] <= start[b + 1];
-          spilled |= fits ? 0u : 1u;
-          lh[b] = fits ? (unsigned)r[i] : SK2_NOFIT;
-        }
+    {  // (small chunks, fewer buckets: one at a time)
+      for (unsigned b = threadIdx.x; b < p1; b += SK2Q_THREADS) {
+        const unsigned v = lh[b];
+        const u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
+        const bool fits = v == 0 || r + v <= start[b + 1];
+        spilled |= fits ? 0u : 1u;
+        lh[b] = fits ? (unsigned)r : SK2_NOFIT;
       }
     }
     __syncthreads();
@@ -453,19 +434,18 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatterq_k(const u64*
           if (i < total) {
             const unsigned it = myq[i];
             const unsigned at = atomicAdd(&lh[it >> 16], 1u);  // base + rank
-            const unsigned src = (wv << 6) | (it & 63u);
-            const ulonglong2 wa = pk_w[st][src];
-            const Sk2Rec rec = sk2_make_record(wa.x, wa.y, pk_w[st][src + 1].y, pk_w[st][src + 2].y, (int)((it >> 6) & 31u),
-                                               (int)((it >> 11) & 31u), k);
+            const u64* const wp = &pk_x[st][wv][it & 63u];
+            const Sk2Rec rec = sk2_make_record(wp[0], wp[1], wp[2], wp[3], (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
             if (at < SK2_NOFIT) part[(size_t)at] = rec;
           }
         }
       } else {
-        const size_t t = (tile * SK2Q_SUBT + st) * SK2_SCAT_THREADS + threadIdx.x;
+        const size_t t = (tile * SK2Q_SUBT + st) * SK2Q_THREADS + threadIdx.x;
         const size_t p0 = t * SK2_R;
         if (p0 < seq_len) {
-          const ulonglong2 wa = pk_w[st][threadIdx.x];
-          const u64 w2 = pk_w[st][threadIdx.x + 1].y, w3 = pk_w[st][threadIdx.x + 2].y;
+          const u64* const wp = &pk_x[st][wv][lane];
+          const ulonglong2 wa = make_ulonglong2(wp[0], wp[1]);
+          const u64 w2 = wp[2], w3 = wp[3];
           const Sk2Runs runs = sk2_analyse(wa.x, wa.y, sk2_valid32(bad, p0, k));
           sk2_walk(runs, wa.x, wa.y, [&](int jstart, int nk, unsigned mm) {
             const unsigned at = atomicAdd(&lh[sk2_bucket(mm, p1_log2)], 1u);
@@ -1072,8 +1052,8 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   else {
     unsigned qcap = SK2Q_CAP;
     if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && v < SK2Q_CAP) qcap = (unsigned)v; }
-    const size_t qtiles = div_up(threads, (size_t)SK2_SCAT_THREADS * SK2Q_SUBT);
-    hipLaunchKernelGGL(mk_sk2_scatterq_k, dim3((unsigned)(qtiles < 4096 ? qtiles : 4096)), dim3(SK2_SCAT_THREADS), 0, c->stream,
+    const size_t qtiles = div_up(threads, (size_t)SK2Q_THREADS * SK2Q_SUBT);
+    hipLaunchKernelGGL(mk_sk2_scatterq_k, dim3((unsigned)(qtiles < 8192 ? qtiles : 8192)), dim3(SK2Q_THREADS), 0, c->stream,
                        (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p,
                        p1_log2, k, qtiles, qcap);
   }
