@@ -518,7 +518,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   c->pending_rows = true;
   if (h->side && h->side >= min_count) c->run_side += h->side;
   if (h->distinct) { c->dup_hint = (double)h->windows / (double)h->distinct; c->dup_known = true; }
-  if (h->records) c->nk_hint = (double)(h->windows + h->exotic) / (double)h->records;
+  if (h->records) { c->nk_hint = (double)(h->windows + h->exotic) / (double)h->records; c->items_hint = (double)h->records * 32.0 / (double)(seq_len ? seq_len : 1); }
   if (getenv("MK_VERBOSE"))
     fprintf(stderr, "[mk] chunk (one read-back): raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu p1=2^%d dup=%.2f nk=%.2f\n",
             n, seq_len, (unsigned long long)h->windows, (unsigned long long)h->records, (unsigned long long)h->distinct,
@@ -713,8 +713,10 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   if (c->h_info->side && c->h_info->side >= min_count) c->run_side += c->h_info->side;
   if (partitioned && c->h_info->distinct) { c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct; c->dup_known = true; }
   if (sk2 && c->h_info->distinct) { c->dup_hint = (double)c->h_info->windows / (double)c->h_info->distinct; c->dup_known = true; }
-  if ((partitioned || sk2) && c->h_info->records)
+  if ((partitioned || sk2) && c->h_info->records) {
     c->nk_hint = (double)(c->h_info->windows + c->h_info->exotic) / (double)c->h_info->records;
+    c->items_hint = (double)c->h_info->records * 32.0 / (double)(seq_len ? seq_len : 1);
+  }
 
   if (getenv("MK_VERBOSE"))
     fprintf(stderr, "[mk] chunk: raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu new_rows=%llu p1=2^%d dup=%.2f nk=%.2f\n", n, seq_len,

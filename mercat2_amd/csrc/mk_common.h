@@ -170,6 +170,7 @@ struct mk_ctx {
   int use_reuse = 1;
   int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
   double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk
+  double items_hint = 0;  // records per analysis thread (32 positions) seen in the previous chunk; 0 = not known yet
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;

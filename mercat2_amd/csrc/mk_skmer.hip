@@ -336,8 +336,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 // queue in LDS at a position from a wave prefix sum -- and the wave then works the queue off 64 items at a time with
 // every lane busy: pass 1 finds each item's bucket (the words of the lane that listed it come from LDS), counts it
 // and writes the bucket into the item; pass 2 needs nothing but the item and those words.  Nothing of the analysis
-// lives across the reservation.  A wave whose runs do not fit its queue (SKQ_CAP items per sub-tile: 8 per lane, the
-// mean is below 5) walks that sub-tile the old way and analyses it again in pass 2 -- rare, content-dependent, exact.
+// lives across the reservation.  A wave whose runs do not fit its queue (8 or 5.9 items per lane, the shape chosen so that the
+// mean is well below) walks that sub-tile the old way and analyses it again in pass 2 -- rare, content-dependent, exact.
 #ifdef MK_STAMP
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
 #define STAMP_ADD(acc, t0) { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; }
@@ -348,9 +348,11 @@ __global__ __launch_bounds__(1024) void mk_sk_scatter_k(const u64* __restrict__ 
 #ifdef MK_STAMP
 __device__ u64 skq_dbg[1024 * 8];  // per workgroup: time of wave 0 in each phase of mk_sk_scatterq_k
 #endif
-#ifndef SKQ_CAP
-#define SKQ_CAP 512
-#endif
+// Two shapes of a tile (template parameters): 2 sub-tiles with 512-item queues (8 items per lane), and 3 sub-tiles with
+// 376-item queues for chunks whose lanes list fewer than ~5.2 records on average (a quarter fewer (tile, bucket)
+// reservations: S2 at k = 31, 4.9 per lane: 10.46-10.79 -> 10.32-10.44 ms per step); either keeps the workgroup's LDS
+// under 80 KB.  The launcher picks by what the chunk before listed (mk_ctx::items_hint).
+#define SKQ_CAP 512      // (the larger of the two: MK_SKQ_CAP is clamped to the shape's own)
 #if defined(SK_ABL_COARSE) && !defined(SK_PLAIN_CURSORS)
 #error "SK_ABL_COARSE needs -DSK_PLAIN_CURSORS (the ablation's region ends differ from the ones sk_reserve8k checks)"
 #endif
@@ -359,7 +361,7 @@ __device__ u64 skq_dbg[1024 * 8];  // per workgroup: time of wave 0 in each phas
 #endif                   // run under the other's analysis; 1024: one workgroup per CU, a quarter fewer reservations
 #define SKQ_WAVES (SKQ_THREADS / 64)
 #define SKQ_WALKED 0xFFFFFFFFu
-template <int W, bool CANON>
+template <int W, bool CANON, int SKQ_SUBT, int SKQ_QCAP>
 __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                          MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                          SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
@@ -367,8 +369,8 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   __shared__ unsigned lh[SK_MAX_P1];  // as above: counts, then base + rank
   // every thread's first word; its second is the next lane's first, and a wave keeps the second word of its last lane
   // itself (pass 1 runs between wave barriers only: a wave must not read what another wave writes)
-  __shared__ u64 pk_x[SK_SCAT_SUBT][SKQ_WAVES][65];
-  __shared__ unsigned queue[SK_SCAT_SUBT][SKQ_WAVES][SKQ_CAP];        // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
+  __shared__ u64 pk_x[SKQ_SUBT][SKQ_WAVES][65];
+  __shared__ unsigned queue[SKQ_SUBT][SKQ_WAVES][SKQ_QCAP];        // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
   __shared__ unsigned s_abort;
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
@@ -385,10 +387,10 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   STAMP(t0);
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     ntile += 1;
-    unsigned qn[SK_SCAT_SUBT];  // items queued per sub-tile (wave-uniform), or SKQ_WALKED
+    unsigned qn[SKQ_SUBT];  // items queued per sub-tile (wave-uniform), or SKQ_WALKED
 #pragma unroll
-    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
-      const size_t t = (tile * SK_SCAT_SUBT + st) * SKQ_THREADS + threadIdx.x;
+    for (int st = 0; st < SKQ_SUBT; ++st) {
+      const size_t t = (tile * SKQ_SUBT + st) * SKQ_THREADS + threadIdx.x;
       const size_t p0 = t * SK_R;
       SkRuns runs;
       runs.valid = 0;
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       }
       const unsigned total = __shfl(inc, 63);
       unsigned* const myq = queue[st][wv];
-      if (total <= qcap) {  // (qcap <= SKQ_CAP; tests lower it to walk some or all waves)
+      if (total <= qcap) {  // (qcap <= SKQ_QCAP; tests lower it to walk some or all waves)
         unsigned todo = s2, at = inc - cnt;
         while (todo) {
           const int j = __ffs(todo) - 1;
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     __syncthreads();
     STAMP_ADD(tD, t0);
 #pragma unroll
-    for (int st = 0; st < SK_SCAT_SUBT; ++st) {
+    for (int st = 0; st < SKQ_SUBT; ++st) {
       if (qn[st] != SKQ_WALKED) {
         const unsigned total = qn[st];
         const unsigned* const myq = queue[st][wv];
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
           }
         }
       } else {
-        const size_t t = (tile * SK_SCAT_SUBT + st) * SKQ_THREADS + threadIdx.x;
+        const size_t t = (tile * SKQ_SUBT + st) * SKQ_THREADS + threadIdx.x;
         const size_t p0 = t * SK_R;
         if (p0 < seq_len) {
           const ulonglong2 w = make_ulonglong2(pk_x[st][wv][lane], pk_x[st][wv][lane + 1]);
@@ -1321,7 +1323,6 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
   const size_t threads = div_up(seq_len, SK_R);
   const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK_HIST_THREADS);
   const size_t stiles = div_up(threads, (size_t)SK_SCAT_THREADS * SK_SCAT_SUBT);
-  const size_t qtiles = div_up(threads, (size_t)SKQ_THREADS * SK_SCAT_SUBT);
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
   const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
   if (!reuse) {  // (reuse: the regions of the previous chunk stand as they are, cursors back at their starts)
@@ -1332,19 +1333,30 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
                        info, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
   }
   static const bool walked = getenv("MK_SCATTER_WALK") != nullptr;  // (the per-lane walks of the first version, for A/B runs)
-  unsigned qcap = SKQ_CAP;
-  if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && v < SKQ_CAP) qcap = (unsigned)v; }
+  // three sub-tiles when the lanes of the chunk before listed few enough records for the shorter queues (mean + 3 sigma
+  // of a wave's total under 376: sigma ~ 2 per lane); MK_SKQ_SUBT=2|3 forces a shape
+  const int force_subt = getenv("MK_SKQ_SUBT") ? atoi(getenv("MK_SKQ_SUBT")) : 0;
+  const bool three = force_subt == 3 || (force_subt != 2 && c->items_hint > 0 && c->items_hint * 64.0 + 48.0 < 376.0);
+  unsigned qcap = three ? 376u : 512u;
+  if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < qcap) qcap = (unsigned)v; }
   if (walked)
     hipLaunchKernelGGL((mk_sk_scatter_k<W, CANON>), dim3((unsigned)(stiles < SK_SCAT_GRID ? stiles : SK_SCAT_GRID)), dim3(SK_SCAT_THREADS), 0,
                        c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
                        (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, stiles, c->canonical);
-  else
-    hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON>), dim3((unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID)), dim3(SKQ_THREADS), 0,
-                       c->stream, (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor,
-                       (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+  else {
+    const size_t qtiles = div_up(threads, (size_t)SKQ_THREADS * (three ? 3 : 2));
+    const dim3 qgrid((unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID));
+    if (three)
+      hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON, 3, 376>), qgrid, dim3(SKQ_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+    else
+      hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON, 2, 512>), qgrid, dim3(SKQ_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+  }
 #ifdef MK_STAMP
   if (!walked) {
     (void)hipStreamSynchronize(c->stream);
+    const size_t qtiles = div_up(threads, (size_t)SKQ_THREADS * (three ? 3 : 2));
     const unsigned g = (unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID);
     std::vector<u64> h(8 * 1024);
     (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(skq_dbg), h.size() * 8);

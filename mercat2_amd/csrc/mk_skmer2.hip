@@ -309,14 +309,14 @@ __global__ __launch_bounds__(SK2_SCAT_THREADS) void mk_sk2_scatter_k(const u64* 
 // words t and t + 1 (its 32 bases and the 32 after them), so its words 2 and 3 are the SECOND words of its two right
 // neighbours: every sub-tile parks its threads' word pairs in LDS plus the pairs of the two threads to its right.  Forward-strand keys only: the canonical analysis files a window under a VALUE, not
 // under a position in its first 32 bases, and keeps the kernel above.
-#define SK2Q_SUBT 2
-#define SK2Q_CAP 512
+#define SK2Q_CAP 512  // (the larger of the two tile shapes: 2 sub-tiles x 512 items, 3 x 376, as in mk_skmer.hip)
 #ifndef SK2Q_THREADS
 #define SK2Q_THREADS 512  // two workgroups per CU, as mk_sk_scatterq_k (72 KB of LDS each)
 #endif
 #define SK2Q_WAVES (SK2Q_THREADS / 64)
 #define SK2Q_WALKED 0xFFFFFFFFu
 #define SK2_NOFIT 0xFF000000u
+template <int SK2Q_SUBT, int SK2Q_QCAP>
 __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                       MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                       SkCursor* __restrict__ cursor, Sk2Rec* __restrict__ part,
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
   // every thread's first word, wave by wave, and the three words after the wave's last lane: a thread's words 1..3 are
   // the first words of the three threads to its right (pass 1 runs between wave barriers only: a wave reads its own row)
   __shared__ u64 pk_x[SK2Q_SUBT][SK2Q_WAVES][67];
-  __shared__ unsigned queue[SK2Q_SUBT][SK2Q_WAVES][SK2Q_CAP];  // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
+  __shared__ unsigned queue[SK2Q_SUBT][SK2Q_WAVES][SK2Q_QCAP];  // items: lane | j << 6 | nk << 11 | (position, then bucket) << 16
   __shared__ unsigned s_abort;
   if (threadIdx.x == 0) s_abort = info->part_overflow != 0;
   __syncthreads();
@@ -1050,12 +1050,18 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     hipLaunchKernelGGL(mk_sk2_scatter_k<false>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
   else {
-    unsigned qcap = SK2Q_CAP;
-    if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && v < SK2Q_CAP) qcap = (unsigned)v; }
-    const size_t qtiles = div_up(threads, (size_t)SK2Q_THREADS * SK2Q_SUBT);
-    hipLaunchKernelGGL(mk_sk2_scatterq_k, dim3((unsigned)(qtiles < 8192 ? qtiles : 8192)), dim3(SK2Q_THREADS), 0, c->stream,
-                       (const u64*)c->codes.p, (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p,
-                       p1_log2, k, qtiles, qcap);
+    const int force_subt = getenv("MK_SKQ_SUBT") ? atoi(getenv("MK_SKQ_SUBT")) : 0;
+    const bool three = force_subt == 3 || (force_subt != 2 && c->items_hint > 0 && c->items_hint * 64.0 + 48.0 < 376.0);
+    unsigned qcap = three ? 376u : 512u;
+    if (const char* e = getenv("MK_SKQ_CAP")) { const int v = atoi(e); if (v >= 0 && (unsigned)v < qcap) qcap = (unsigned)v; }
+    const size_t qtiles = div_up(threads, (size_t)SK2Q_THREADS * (three ? 3 : 2));
+    const dim3 qgrid((unsigned)(qtiles < 8192 ? qtiles : 8192));
+    if (three)
+      hipLaunchKernelGGL((mk_sk2_scatterq_k<3, 376>), qgrid, dim3(SK2Q_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap);
+    else
+      hipLaunchKernelGGL((mk_sk2_scatterq_k<2, 512>), qgrid, dim3(SK2Q_THREADS), 0, c->stream, (const u64*)c->codes.p,
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap);
   }
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);

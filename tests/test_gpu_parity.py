@@ -825,6 +825,34 @@ def test_scatter_queue_and_walk_agree(monkeypatch, qcap, walk):
         assert got == want, (k, c, canon, qcap)
 
 
+@pytest.mark.parametrize("qcap", [None, "250"])
+def test_scatter_tile_shapes_agree(monkeypatch, qcap):
+    """The queue scatter has two tile shapes -- 2 sub-tiles with 512-item queues, 3 with 376-item queues, picked from
+    what the chunk before listed per lane (MK_SKQ_SUBT forces one).  Three sub-tiles on a first chunk, on input whose
+    waves overflow the shorter queues (k = 12, 14: many runs per lane; the poly-A and repeat records: few), with the
+    queue cut down further, and over several chunks so that the hint switches shapes by itself: same tables."""
+    from oracle import c_oracle
+    if qcap is not None:
+        monkeypatch.setenv("MK_SKQ_CAP", qcap)
+    data = native.synth_reads(300_000, 5, 70_000, 150, 6).tobytes()
+    low = b">poly\n" + b"A" * 20_000 + b"\n>n\n" + (b"ACGTTGCAAGGCTTAACGGATCCATGCAAGTCCN" * 1500) + b"\n"
+    payload = data + low
+    for k, c, canon in ((31, 1, False), (21, 2, False), (12, 2, False), (14, 1, True), (32, 2, True), (63, 1, False), (40, 2, False)):
+        want = _fold_filter(c_oracle.count_dict(payload, k, 0), c) if canon else c_oracle.count_dict(payload, k, c)
+        monkeypatch.setenv("MK_SKQ_SUBT", "3")
+        with native.Counter(k, native.ALPHABET_NT2, canonical=canon) as ctx:
+            ctx.count_chunk(payload, c)
+            got = ctx.to_dict()
+        assert got == want, (k, c, canon, qcap, "forced 3")
+        monkeypatch.delenv("MK_SKQ_SUBT")
+        if c == 1:  # three equal chunks: the second and third take whatever shape the first one's records suggest
+            with native.Counter(k, native.ALPHABET_NT2, canonical=canon) as ctx:
+                for _ in range(3):
+                    ctx.count_chunk(payload, 1)
+                got3 = ctx.to_dict()
+            assert got3 == {key: 3 * n for key, n in want.items()}, (k, canon, qcap, "by hint")
+
+
 @pytest.mark.parametrize("nkmax", ["1", "3", "5", "12", "31"])
 def test_record_length_limit_is_only_a_layout_choice(monkeypatch, nkmax):
     """Runs of windows that share a minimizer are cut into records of at most 8 windows (MK_NKMAX moves the limit:
