@@ -366,9 +366,17 @@ extern "C" int mk_chunk_feed_device(mk_ctx* c, const uint8_t* d_text, size_t n) 
 }
 
 // ------------------------------------------------------------------------ running tables
+// Slots of a running table that has to take need_rows rows: the next power of two above 2.5 x (load 20-40 % after a
+// growth, 50 % before the next; MK_GROW_X4=1: above 4 x, as in rounds 1-2).  Compaction, table-to-table sums and
+// clears scan the slots, so a table twice as sparse costs every sample ~0.15 ms.
+static size_t run_slots_for(size_t need_rows) {
+  static const bool x4 = getenv("MK_GROW_X4") != nullptr;
+  return pow2_at_least(x4 ? 4 * need_rows : need_rows * 5 / 2);
+}
+
 static int grow_run64(mk_ctx* c, size_t need_rows) {
   if (2 * need_rows <= c->run_slots) return MK_OK;
-  const size_t slots = pow2_at_least(4 * need_rows);
+  const size_t slots = run_slots_for(need_rows);
   MkDevBuf nb;
   int rc = mk_buf_reserve(c, nb, slots * sizeof(MkSlot));
   if (rc) return rc;
