@@ -205,6 +205,10 @@ def main():
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N driven by THIS one process through the C ABI (mk_merge_devices: peer copies over xGMI) "
                          "instead of one process per GPU over RCCL")
+    ap.add_argument("--merge-rccl", action="store_true",
+                    help="--single-process: the segments of mk_merge_devices travel over RCCL (MK_MERGE_RCCL) instead of peer copies")
+    ap.add_argument("--no-single-leg", action="store_true",
+                    help="N > 1, one process per GPU: do not run the one-process product path (mk_merge_devices) in a fresh child afterwards")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the cpu_baseline leg (default: the physical cores available)")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of the other BASELINE configs after the main region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -292,6 +296,7 @@ def main():
             self.out = [(torch.empty(cap * self.words, dtype=torch.int64, device="cuda:%d" % d),
                          torch.empty(cap, dtype=torch.int64, device="cuda:%d" % d)) for d in devices]
             self.merge_stats = None
+            self.phase = {"count_s": 0.0, "merge_s": 0.0, "export_s": 0.0, "steps": 0}  # this process, summed over steps
 
         def close(self):
             if self.pool:
@@ -320,7 +325,12 @@ def main():
             def export_device(di):
                 return self.leaders[di].export_pairs_device(self.out[di][0].data_ptr(), self.out[di][1].data_ptr(), self.out_cap)
 
+            merge_flags = native.MERGE_RANGES | native.MERGE_BALANCED | (native.MERGE_RCCL if args.merge_rccl else 0)
+
             def step():
+                # (every phase ends with a host wait of its own -- the last chunk's read-back, the merge's import, the
+                # export's row count -- so plain clocks split the step without adding a synchronisation to it)
+                t0 = time.perf_counter()
                 if self.pool is None:
                     count_share(jobs[0])
                 else:
@@ -329,13 +339,24 @@ def main():
                     finish_device(0)
                 else:
                     list(self.pool.map(finish_device, range(len(devices))))
-                    # one process, several GPUs: key-range ownership, peer copies, import at the owners (mk_multi.hip)
-                    self.merge_stats = native.merge_devices(self.leaders, native.MERGE_RANGES | native.MERGE_BALANCED)
+                t1 = time.perf_counter()
+                if len(devices) > 1:
+                    # one process, several GPUs: key-range ownership, peer copies (or RCCL), import at the owners (mk_multi.hip)
+                    self.merge_stats = native.merge_devices(self.leaders, merge_flags)
                 if world > 1:
                     merge_ranks(self.leaders[0], self.key_bits, device=dev)
+                t2 = time.perf_counter()
                 if len(devices) == 1:
-                    return export_device(0)
-                return sum(self.pool.map(export_device, range(len(devices))))  # every owner sorts its own range
+                    rows = export_device(0)
+                else:
+                    rows = sum(self.pool.map(export_device, range(len(devices))))  # every owner sorts its own range
+                t3 = time.perf_counter()
+                ph = self.phase
+                ph["count_s"] += t1 - t0
+                ph["merge_s"] += t2 - t1
+                ph["export_s"] += t3 - t2
+                ph["steps"] += 1
+                return rows
             return step
 
     # ---- synthetic input: generate on the host, cut like the reference Chunker, move to HBM
@@ -374,6 +395,7 @@ def main():
             for c in eng.all:
                 c.reset_stats()
                 c.set_profiling(True)
+        eng.phase.update(count_s=0.0, merge_s=0.0, export_s=0.0, steps=0)
         fence()
         t0 = time.perf_counter()
         rows = 0
@@ -394,24 +416,48 @@ def main():
         for other in stats[1:]:
             for key, val in other.items():
                 if key.startswith(("ms_", "n_")) or key in ("windows", "exotic_windows", "symbols", "raw_bytes", "chunks", "records", "distinct",
-                                                              "part_retries", "part_reused"):
+                                                              "part_retries", "part_reused", "fused_chunks", "fuse_spilled"):
                     st[key] += val
         return st
 
-    # the reference's table of this exact workload (tests/golden/expected_s2.json, made by tests/golden/make_s2_golden.py)
-    golden_rows = {}
+    # the reference's tables of the BASELINE workloads (tests/golden/expected_s2.json, made by tests/golden/make_s2_golden.py
+    # from the reference's own Chunker + find_kmers): rows, sum of counts, sha256 of the concatenated keys and of the counts
+    golden = {}
     try:
-        gj = json.loads((ROOT / "tests" / "golden" / "expected_s2.json").read_text())["S2|k31|c10|s100"]
-        golden_rows = {False: gj["forward"]["rows"], True: gj["canonical"]["rows"]}
+        gj = json.loads((ROOT / "tests" / "golden" / "expected_s2.json").read_text())
+        for name, wl in (("S2|k31|c10|s100", (READS, GENOME, K, GENOME_SEED, READ_SEED)),
+                         ("S1|k21|c10|s100", (1_000_000, 1_000_000, 21, 1, 2)),
+                         ("S3|k63|c10|s100", (50_000_000, 50_000_000, 63, 6, 7))):
+            if name in gj:
+                for canon, tab in ((False, "forward"), (True, "canonical")):
+                    if tab in gj[name]:
+                        golden[wl + (canon,)] = gj[name][tab]
     except (OSError, KeyError, ValueError):
         pass
 
-    def verify_rows(rows, mode, reads, genome, kk, sub_ppm, canon, gseed, rseed):
-        """True/False when this run is the S2 sample whose table the reference produced; None when it is another workload."""
-        is_ref = (reads, genome, kk, sub_ppm, gseed, rseed) == (READS, GENOME, K, 0, GENOME_SEED, READ_SEED) and (ngpu == 1 or mode == "strong")
-        if not is_ref or canon not in golden_rows:
+    def golden_for(mode, reads, genome, kk, sub_ppm, canon, gseed, rseed):
+        if sub_ppm or not (ngpu == 1 or mode == "strong"):
             return None
-        return rows == golden_rows[canon]
+        return golden.get((reads, genome, kk, gseed, rseed, bool(canon)))
+
+    def verify_rows(rows, mode, reads, genome, kk, sub_ppm, canon, gseed, rseed):
+        """True/False when this run is a sample whose table the reference produced; None when it is another workload."""
+        g = golden_for(mode, reads, genome, kk, sub_ppm, canon, gseed, rseed)
+        return None if g is None else rows == g["rows"]
+
+    def verify_table(eng_, mode, reads, genome, kk, sub_ppm, canon, gseed, rseed):
+        """After a timed region: the table the last step left (one GPU: in the leader context), exported once more
+        through mk_export and compared with the reference's -- rows, sum of counts, sha256 of keys and counts.
+        {"rows": bool, "sum": bool, "digest": bool} or None when the reference holds no table for this workload."""
+        import hashlib
+        g = golden_for(mode, reads, genome, kk, sub_ppm, canon, gseed, rseed)
+        if g is None or ngpu != 1:
+            return None
+        kmers, counts = eng_.leaders[0].export()
+        res = {"rows": int(counts.shape[0]) == g["rows"], "sum": int(counts.sum()) == g["sum"]}
+        res["digest"] = (hashlib.sha256(kmers.tobytes()).hexdigest() == g["keys_sha256"] and
+                         hashlib.sha256(counts.astype("<u8").tobytes()).hexdigest() == g["counts_sha256"])
+        return res
 
     mode = args.scaling if ngpu > 1 else "weak"
     eng = Engine(k, canonical, args.genome, args.sub_ppm)
@@ -422,7 +468,24 @@ def main():
     for c in eng.all:
         c.set_profiling(False)
     main_merge_stats = eng.merge_stats
+    # per-rank phases of the timed region (DESIGN section 6 holds the model they are to be read against)
+    from mercat2_amd import dist as mkdist
+    n_ph = max(1, eng.phase["steps"])
+    mine = {"rank": rank, "device": local, "count_ms": eng.phase["count_s"] / n_ph * 1e3, "merge_ms": eng.phase["merge_s"] / n_ph * 1e3,
+            "export_ms": eng.phase["export_s"] / n_ph * 1e3, "rows_owned": None, "wire_bytes_sent": 0, "wire_bytes_received": 0}
+    if world > 1 and mkdist.LAST_MERGE:
+        lm = mkdist.LAST_MERGE
+        mine.update(rows_owned=lm["rows_owned"], wire_bytes_sent=lm["wire_bytes_sent"], wire_bytes_received=lm["wire_bytes_received"],
+                    merge_bucket_ms=lm["bucket_s"] * 1e3, merge_collectives_ms=lm["collectives_s"] * 1e3, merge_import_ms=lm["import_s"] * 1e3)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        with torch.cuda.device(dev):
+            dist.all_gather_object(per_rank, mine)
     verified = verify_rows(total_rows, mode, args.reads, args.genome, k, args.sub_ppm, canonical, args.genome_seed, args.read_seed)
+    verified_table = verify_table(eng, mode, args.reads, args.genome, k, args.sub_ppm, canonical, args.genome_seed, args.read_seed) if rank == 0 else None
+    if verified_table is not None and not all(verified_table.values()):
+        verified = False
 
     # After the timed region: the same kernels alone on the GPU (one context, one pass), so that the
     # dominant kernel's duration can also be read without the other stream's kernels on its CUs.
@@ -475,6 +538,11 @@ def main():
                                  "mode": s2["mode_name"], "count_kernel_ms_per_launch": ms_l, "count_kernel_frac": ach / HBM_PEAK_GBS,
                                  "bytes_per_window": bpw,
                                  "verified_rows": verify_rows(rows2, "weak", reads, genome, kk, 0, canon, gseed, rseed)}
+                vt = verify_table(e2, "weak", reads, genome, kk, 0, canon, gseed, rseed)
+                if vt is not None:
+                    configs[name]["verified_sum"], configs[name]["verified_digest"] = vt["sum"], vt["digest"]
+                    if not all(vt.values()):
+                        configs[name]["verified_rows"] = False
                 del p2
             finally:
                 e2.close()
@@ -487,6 +555,8 @@ def main():
         torch.cuda.empty_cache()
         short_run("config2_s1_k21", 21, False, 1_000_000, 1_000_000, 1, 2, max(2, args.steps))
         short_run("config5_s3_k63", 63, False, 50_000_000, 50_000_000, 6, 7, 3)
+        if any(c_["verified_rows"] is False for c_ in configs.values()):
+            verified = False
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -541,7 +611,12 @@ def main():
             "rows": total_rows,
             # the rows the REFERENCE gets for this sample (tests/golden/expected_s2.json); null when the run is not that sample
             "verified_rows": verified,
+            # the table of the last timed step exported once more and compared with the reference's sum and sha256 digests
+            "verified_sum": None if verified_table is None else verified_table["sum"],
+            "verified_digest": None if verified_table is None else verified_table["digest"],
             "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "part", "count", "exotic", "filter", "export")},
+            # chunks whose count kernel merged its survivors into the running table itself (no import kernel), and what those set aside
+            "fused_chunks_per_step": st["fused_chunks"] / args.steps, "fuse_spilled": st["fuse_spilled"],
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "ms_per_launch": ms_launch,
@@ -593,15 +668,61 @@ def main():
                 line["file_to_tsv"]["gz_vs_cpu_baseline"] = line["file_to_tsv"]["gz_bases_per_s"] / cpu
                 line["file_to_tsv"]["vs_cpu_note"] = ("the CPU figure is counting only (text already in memory): against a "
                                                       "CPU run that also had to inflate the .gz the ratio would be larger")
-        print(json.dumps(line))
-        sys.stdout.flush()
+        line["per_rank"] = per_rank
     eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and not args.no_single_leg:
+            # every rank has closed its contexts: the GPUs are idle.  The product's own N-GPU path -- ONE process, chunks
+            # dealt to the GPUs through the C ABI, mk_merge_devices -- timed in a fresh child process of this one (never
+            # an exec of this process), its line folded in here
+            line["also_single_process"] = single_process_leg(args, backend)
+        print(json.dumps(line))
+        sys.stdout.flush()
     if verified is False:
-        raise SystemExit("bench.py: the table of the timed workload has %d rows, the reference's table of the same sample has %s: "
-                         "the result is WRONG" % (total_rows, golden_rows.get(canonical)))
+        raise SystemExit("bench.py: a table of a timed workload differs from the reference's table of the same sample "
+                         "(rows %d; verified_table %s; configs %s): the result is WRONG"
+                         % (total_rows, verified_table, {n_: c_.get("verified_rows") for n_, c_ in (configs or {}).items()}))
+
+
+def single_process_leg(args, backend):
+    """`bench.py --gpus N --single-process` in a child process; the figures of its line that say how the one-process path
+    did (value, step, phases of mk_merge_devices, peer access), or {"error": ...}: never fails the parent's line."""
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--gpus", str(args.gpus), "--single-process", "--steps", str(args.steps),
+           "--warmup", "1", "--scaling", args.scaling, "--reads", str(args.reads), "--k", str(args.k), "--genome", str(args.genome),
+           "--genome-seed", str(args.genome_seed), "--read-seed", str(args.read_seed), "--sub-ppm", str(args.sub_ppm),
+           "--no-also", "--no-configs", "--no-cpu", "--no-file-leg"]
+    if args.canonical:
+        cmd.append("--canonical")
+    if args.contexts > 0:
+        cmd += ["--contexts", str(args.contexts)]
+    env = {k_: v_ for k_, v_ in os.environ.items()
+           if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MK_BENCH_CHILD", "GROUP_RANK",
+                         "ROLE_RANK", "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    if backend != "nccl":
+        env["MK_BENCH_SHARE_DEVICE"] = "1"  # (a rehearsal on fewer GPUs than ranks stays one)
+    out = {}
+    for label, extra in (("peer_copies", []), ("rccl", ["--merge-rccl"])):
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.rank_timeout)
+            lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                out[label] = {"error": "exit %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
+                continue
+            j = json.loads(lines[-1])
+            out[label] = {key: j.get(key) for key in ("value", "unit", "ms_per_step", "n_gpus", "scaling", "rows", "verified_rows",
+                                                      "merge_devices", "per_rank", "steps", "warmup")}
+            out[label]["wall_s"] = time.perf_counter() - t0
+        except subprocess.TimeoutExpired:
+            out[label] = {"error": "no line within --rank-timeout %d s (the child was killed)" % args.rank_timeout}
+        except (OSError, ValueError) as e:
+            out[label] = {"error": repr(e)[:300]}
+    out["note"] = "one process drives all GPUs through the C ABI (mk_count_device per chunk, mk_merge_devices, mk_export per " \
+                  "owner); run in a fresh child after the ranks had closed their contexts; 1 warm-up step"
+    return out
 
 
 def file_to_tsv_leg(args, k, canonical):
@@ -630,21 +751,32 @@ def file_to_tsv_leg(args, k, canonical):
         del data
         res = {}
         for name, path in (("plain", plain), ("gz", gz)):
-            best, st_best, rows = None, None, 0
+            best, st_best, tm_best, rows = None, None, None, 0
             for _ in range(2):
-                st = {}
+                st, tm = {}, {}
                 out = os.path.join(d, "S2_counts.tsv")
                 lines = []
                 t0 = time.perf_counter()
-                harness.run_sample("S2", path, out, k, MIN_COUNT, CHUNK_MIB, canonical=canonical, stats=st, report=lines.append)
+                harness.run_sample("S2", path, out, k, MIN_COUNT, CHUNK_MIB, canonical=canonical, stats=st, report=lines.append, timings=tm)
                 dt = time.perf_counter() - t0
                 if best is None or dt < best:
-                    best, st_best = dt, st
+                    best, st_best, tm_best = dt, st, tm
                 rows = int(lines[0].split(":")[1]) if lines and ":" in lines[0] else 0
             res[name + "_s"] = best
             res[name + "_bases_per_s"] = args.reads * READ_LEN / best
             res[name + "_threads"] = st_best.get("threads")
             res[name + "_file_bytes"] = os.path.getsize(path)
+            # where the window went (seconds; mk_file_stats_t + mk_export_stats_t): the parts of the DISPATCHING thread of
+            # mk_count_file add up to count_file; count_file + tsv + other = the window
+            ex = tm_best.get("export", {})
+            parts = {"count_file": st_best.get("s_total"),
+                     "count_file_parts": {n_[2:]: st_best.get(n_) for n_ in ("s_setup", "s_wait_io", "s_wait_gpu", "s_scan", "s_feed",
+                                                                             "s_retire", "s_drain", "s_merge")},
+                     "tsv": tm_best.get("tsv_s"),
+                     "tsv_parts": {n_[2:]: ex.get(n_) for n_ in ("s_sort", "s_d2h", "s_format", "s_write")},
+                     "tsv_bytes": ex.get("bytes")}
+            parts["other"] = best - (parts["count_file"] or 0.0) - (parts["tsv"] or 0.0)  # contexts taken / given back, Python
+            res[name + "_breakdown_s"] = parts
             res["rows"] = rows
         res["bases_per_s"] = res["plain_bases_per_s"]
         res["threads"] = res["plain_threads"]

@@ -71,6 +71,8 @@ typedef struct mk_stats_t {
   uint64_t distinct; /* distinct packed keys seen per chunk, summed over chunks */
   uint64_t part_retries; /* chunks partitioned twice: the sampled bucket sizes were too small somewhere */
   uint64_t part_reused;  /* chunks that inherited the bucket regions of the chunk before them (no histogram, no scan) */
+  uint64_t fused_chunks; /* chunks whose count kernel put the survivors into the running table itself (ABI 4)        */
+  uint64_t fuse_spilled; /* ... survivors of those it set aside instead (table filling up), imported afterwards        */
 } mk_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */
@@ -113,7 +115,9 @@ typedef struct mk_clean_gpu_t {
   uint64_t raw_bytes;    /* bytes of the chunks counted in clean mode since mk_reset                              */
   uint64_t symbols;      /* sequence characters kept (N runs excluded): the total_length removeN divides by,
                             without the header lines of split records                                            */
-  uint64_t gc_count;     /* 'G' + 'C' among them (after -toupper if it is on)                                     */
+  uint64_t gc_count;     /* 'G' + 'C' among them AFTER -toupper if it is on, header lines of split records not
+                            included: NOT the reference's "GC Content" figure, which counts before upper-casing and
+                            includes those header lines (lib/mercat2_fasta.py:92-113; mk_remove_n reports that one) */
   uint64_t n_bytes;      /* upper-case 'N' bytes removed                                                         */
   uint64_t n_runs;       /* runs of N = cuts = pieces added                                                      */
   uint64_t header_lines; /* records                                                                             */
@@ -121,8 +125,9 @@ typedef struct mk_clean_gpu_t {
 } mk_clean_gpu_t;
 int mk_clean_stats(mk_ctx* ctx, mk_clean_gpu_t* out);
 /* The N runs of the last chunk as [starts[i], ends[i]) in the parsed stream (kept characters in order, one separator
- * per header line: the stream the k-mer windows slide over), ascending; *n = how many (cap values fit; at most 65536
- * are kept per chunk).  What split_sequenceN cuts at (lib/mercat2_fasta.py:35-38). */
+ * per header line: the stream the k-mer windows slide over), ascending; *n = how many (cap values fit).  A chunk with
+ * more than 65536 runs is not listed: MK_ERR_RANGE, *n = 0 (mk_clean_stats still counts them).  What split_sequenceN
+ * cuts at (lib/mercat2_fasta.py:35-38). */
 int mk_clean_runs(mk_ctx* ctx, uint64_t* starts, uint64_t* ends, size_t cap, size_t* n);
 
 /* ---- one chunk = one find_kmers call (lib/mercat2_kmers.py:32-78) ------------------------ */
@@ -159,6 +164,13 @@ typedef struct mk_file_stats_t {
   double s_wait_gpu;   /* seconds it waited for a context to finish its previous chunk       */
   double s_total;      /* wall seconds of the call                                           */
   double s_merge;      /* of those, the sum of the contexts' tables at the end                */
+  /* (ABI 4) where the dispatching thread's time went; s_setup + s_wait_io + s_wait_gpu + s_scan + s_feed + s_retire +
+   * s_drain + s_merge ~= s_total */
+  double s_setup;      /* open, ring (pinned memory), worker and reader threads started       */
+  double s_scan;       /* the Chunker rule applied to the blocks                              */
+  double s_feed;       /* inside the host-to-device copy calls                                */
+  double s_retire;     /* waiting for copies out of ring blocks the readers want back         */
+  double s_drain;      /* after the last block: copies, readers and the last chunks' counting */
 } mk_file_stats_t;
 /* Reads `path` (gzip iff its name ends in ".gz", as the reference decides), splits it as
  * Chunker(path, dest, chunk_bytes, '>') would iff its on-disk size is >= chunk_bytes > 0
@@ -184,6 +196,19 @@ int mk_export(mk_ctx* ctx, uint8_t* kmers, uint64_t* counts, size_t rows_cap);
 /* Writes "k-mer\t{basename}_Count\n" + rows; writes NO file and sets *rows = 0 when the
  * table is empty (bin/mercat2.py:128-137). */
 int mk_write_tsv(mk_ctx* ctx, const char* path, const char* basename, size_t* rows);
+
+/* Where the last mk_export / mk_write_tsv of this context spent its time (the sorted() + print loop of
+ * bin/mercat2.py:130-133 is as expensive as the counting for the reference: 17 s + 13 s at 7.7 M rows). */
+typedef struct mk_export_stats_t {
+  uint64_t rows;     /* rows exported (packed + kept as text)                                         */
+  uint64_t bytes;    /* bytes of TSV text written (0 for mk_export)                                   */
+  double s_sort;     /* device: compaction of the table + radix sort of the packed keys, waited for   */
+  double s_d2h;      /* sorted rows to the host (+ the rows kept as text, sorted on the device)         */
+  double s_format;   /* host: keys decoded to text, counts to decimal, merged with the text rows       */
+  double s_write;    /* host: inside write(2) (the file is written while it is formatted)               */
+  double s_total;
+} mk_export_stats_t;
+int mk_export_stats(mk_ctx* ctx, mk_export_stats_t* out);
 
 /* ---- several samples side by side: merge_tsv (lib/mercat2_report.py:98-156) from the tables --- */
 /* The combined table of n samples (contexts with the same k; each on its own GPU or all on one):
@@ -271,6 +296,9 @@ int mk_dense_bins_device(mk_ctx* ctx, uint64_t* d_bins, size_t nbins, int store)
 #define MK_MERGE_GATHER 1   /* afterwards ctxs[0] holds every row and the others are empty                        */
 #define MK_MERGE_BALANCED 2 /* (with RANGES) owner bounds from a sample of the keys (about equal rows per owner)
                                instead of equal key ranges                                                        */
+#define MK_MERGE_RCCL 4     /* the segments travel by grouped ncclSend / ncclRecv (RCCL over xGMI; one communicator per
+                               GPU, made on first use) instead of peer copies; MK_ERR_UNSUPPORTED when librccl.so cannot
+                               be loaded                                                                          */
 typedef struct mk_merge_stats_t {
   uint64_t rows_in;      /* rows of all contexts before the merge (the same key counted once per context) */
   uint64_t rows_out;     /* rows of all contexts after it (distinct keys)                                  */
@@ -279,7 +307,7 @@ typedef struct mk_merge_stats_t {
   uint64_t max_owned;    /* rows of the fullest owner afterwards                                            */
   int32_t contexts, devices;
   int32_t peer_direct;   /* device pairs with direct peer access (xGMI) among the pairs that exchanged rows */
-  int32_t pad_;
+  int32_t rccl;          /* 1: the rows travelled over RCCL (MK_MERGE_RCCL)                                  */
   double s_bucket, s_copy, s_import, s_total; /* wall seconds of the phases */
 } mk_merge_stats_t;
 /* Sum the running tables of n contexts (same alphabet, k, canonical mode; on n different GPUs, or several on one)

@@ -6,6 +6,7 @@
 // Export == sorted(kmers.items()) + the TSV print loop (bin/mercat2.py:128-137).
 #include "mk_common.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -103,7 +104,7 @@ static void prof_collect(mk_ctx* c) {
 // ----------------------------------------------------------------------------- lifetime
 // "mercat_hip <abi>.<minor> (gfx950)": the ABI number changes whenever a struct or a signature of include/mercat_hip.h does
 // (native.py checks it against its own MK_ABI before it trusts the struct layouts)
-extern "C" const char* mk_version(void) { return "mercat_hip 3.0 (gfx950)"; }
+extern "C" const char* mk_version(void) { return "mercat_hip 4.0 (gfx950)"; }
 
 extern "C" int mk_device_count(void) {
   int n = 0;
@@ -192,6 +193,7 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
     return fail(MK_ERR_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e));
   c->use_speculation = getenv("MK_NO_SPECULATION") ? 0 : 1;
   c->use_reuse = getenv("MK_NO_REUSE") ? 0 : 1;
+  c->use_fused = getenv("MK_NO_FUSE") ? 0 : 1;
   if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo) + 8 * sizeof(u64), hipHostMallocDefault)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
   c->h_clean = (u64*)(c->h_info + 2);
@@ -257,6 +259,8 @@ static int reset_impl(mk_ctx* c, size_t expect_rows) {
   c->raw_len = 0;
   c->part_reuse_ok = false;  // (a new sample sizes its own bucket regions: nothing is inherited across samples)
   c->dup_known = false;
+  c->surv_hint_ok = false;   // (... and its first chunk hands its survivors over through their regions: their number is not known)
+  c->fuse_cap = 0;
   c->clean_n_runs = c->clean_n_bytes = c->clean_gc = c->clean_symbols = c->clean_raw = c->clean_headers = c->clean_last_runs = 0;
   MK_HIP(hipStreamSynchronize(c->stream));
   return MK_OK;
@@ -306,7 +310,14 @@ extern "C" int mk_clean_stats(mk_ctx* c, mk_clean_gpu_t* out) {
 
 extern "C" int mk_clean_runs(mk_ctx* c, uint64_t* starts, uint64_t* ends, size_t cap, size_t* n) {
   if (!c || !n || (cap && (!starts || !ends))) return MK_ERR_ARG;
-  const size_t kept = std::min<size_t>((size_t)c->clean_last_runs, (size_t)1 << 16);
+  // (the kernel lists run starts and run ends apart, each up to the lists' capacity: past it the two lists would not
+  // hold the same runs, and pairing them by rank would invent intervals -- refuse instead of returning a wrong list)
+  if ((size_t)c->clean_last_runs > ((size_t)1 << 16)) {
+    *n = 0;
+    c->err = "mk_clean_runs: the last chunk holds " + std::to_string(c->clean_last_runs) + " runs of N, more than the 65536 the list keeps";
+    return MK_ERR_RANGE;
+  }
+  const size_t kept = (size_t)c->clean_last_runs;
   *n = kept;
   if (!kept || !cap) return MK_OK;
   MK_HIP(hipSetDevice(c->device));
@@ -460,8 +471,23 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   c->rtab_chunk_slots = 0;
   c->surv_regions = 0;
   c->ctab_slots = 0;
+  // Fused upsert (mk_skcount.hip): from a sample's second chunk on the count kernel puts the survivors into the running
+  // table itself -- no import kernel, no waiting for their number.  The table is sized HERE for what the chunk before
+  // kept, twice over; the kernel spills what a table that fills up all the same cannot take, and that is imported below.
+  c->fuse_cap = 0;
+  if (!two && c->use_fused && min_count >= 2 && c->surv_hint_ok && !c->run_bucket_major) {
+    const unsigned long long per_bucket = c->surv_hint >> 13;  // (8192 buckets on chunks of this size; smaller chunks: fewer of both)
+    const int cap = per_bucket <= 110 ? 512 : (per_bucket <= 360 ? 1024 : 0);
+    if (cap) {
+      if ((rc = settle(c)) != MK_OK) return rc;  // (run_rows must be what the table holds)
+      if ((rc = grow_run64(c, c->run_rows + 2 * (size_t)c->surv_hint + 4096)) != MK_OK) return rc;
+      c->fuse_cap = cap;
+    }
+  }
   rc = two ? mk_launch_count_superkmer2(c, n, min_count) : mk_launch_count_superkmer(c, n, min_count);  // (seq_len <= n)
+  c->fuse_cap = 0;
   if (rc) return rc;
+  const bool fused = !two && c->fused_last;
   if ((rc = pull_info(c)) != MK_OK) return rc;  // the one read-back
   MkChunkInfo* h = c->h_info;
   if (h->parse_fallback) return MK_RETRY_GENERAL;
@@ -495,6 +521,8 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     h->windows = h->records = h->distinct = h->survivors = h->side = h->errors = h->part_overflow = 0;
     MK_HIP(hipMemcpyAsync(c->info.p, h, sizeof(MkChunkInfo), hipMemcpyHostToDevice, c->stream));
     c->st.part_retries += 1;
+    // (a fused count kernel that met the flag stopped before its first bucket: the running table is as it was; the exact
+    // pass hands its survivors over through their regions)
     rc = two ? mk_launch_count_superkmer2(c, seq_len, min_count, /*exact=*/true) : mk_launch_count_superkmer(c, seq_len, min_count, /*exact=*/true);
     if (rc) return rc;
     if ((rc = pull_info(c)) != MK_OK) return rc;
@@ -505,11 +533,25 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     return MK_ERR_RANGE;
   }
   c->part_dirty = false;  // the count kernel ran to its end: every cursor is back at its region's start
-  if (!two && h->survivors && (rc = grow_run64(c, c->run_rows + (size_t)h->survivors)) != MK_OK) return rc;
+  const bool fused_done = !two && c->fused_last;  // (of the launch that counted: the exact pass is never fused)
+  if (fused_done) {
+    c->run_rows += (size_t)h->new_rows;  // (counted by the kernel, in the same read-back)
+    h->new_rows = 0;
+    c->st.fused_chunks += 1;
+    c->st.fuse_spilled += h->spilled;
+    // (what is launched below adds to the device's copy again, and that copy is read back later: start it from zero)
+    MK_HIP(hipMemsetAsync(&((MkChunkInfo*)c->info.p)->new_rows, 0, sizeof(unsigned long long), c->stream));
+    if (h->spilled) {  // the table was filling up: what the kernel set aside goes in now, into a table with room
+      if ((rc = grow_run64(c, c->run_rows + (size_t)h->spilled)) != MK_OK) return rc;
+      if ((rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)h->spilled)) != MK_OK) return rc;
+    }
+  }
+  (void)fused;
+  if (!two && !fused_done && h->survivors && (rc = grow_run64(c, c->run_rows + (size_t)h->survivors)) != MK_OK) return rc;
   if (h->survivors_ref && (rc = grow_run_ref(c, c->run_ref_rows + (size_t)h->survivors_ref)) != MK_OK) return rc;
   if (two && (h->survivors || h->survivors_ref) &&
       (rc = grow_run128(c, c->run128_rows + (size_t)h->survivors + (size_t)h->survivors_ref)) != MK_OK) return rc;
-  if (h->survivors && seq_len) {
+  if (h->survivors && seq_len && !fused_done) {
     const size_t p1 = (size_t)1 << c->p1_log2;
     const uint64_t* meta = (const uint64_t*)c->part_meta.p;  // hist|start|cursor|khist|kstart|kcursor|nsurv
     mk_prof_begin(c, MK_K_FILTER);
@@ -525,12 +567,14 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   MK_HIP(hipMemcpyAsync(c->h_info + 1, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
   c->pending_rows = true;
   if (h->side && h->side >= min_count) c->run_side += h->side;
+  if (!two) { c->surv_hint = h->survivors; c->surv_hint_ok = true; }
   if (h->distinct) { c->dup_hint = (double)h->windows / (double)h->distinct; c->dup_known = true; }
   if (h->records) { c->nk_hint = (double)(h->windows + h->exotic) / (double)h->records; c->items_hint = (double)h->records * 32.0 / (double)(seq_len ? seq_len : 1); }
   if (getenv("MK_VERBOSE"))
-    fprintf(stderr, "[mk] chunk (one read-back): raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu p1=2^%d dup=%.2f nk=%.2f\n",
+    fprintf(stderr, "[mk] chunk (one read-back): raw=%zu seq=%zu windows=%llu records=%llu distinct=%llu survivors=%llu p1=2^%d dup=%.2f nk=%.2f fused=%d spilled=%llu rows=%zu slots=%zu\n",
             n, seq_len, (unsigned long long)h->windows, (unsigned long long)h->records, (unsigned long long)h->distinct,
-            (unsigned long long)h->survivors, c->p1_log2, c->dup_hint, c->nk_hint);
+            (unsigned long long)h->survivors, c->p1_log2, c->dup_hint, c->nk_hint, fused_done ? 1 : 0, (unsigned long long)h->spilled,
+            c->run_rows, c->run_slots);
   c->st.table_slots = c->rtab_chunk_slots;
   c->st.raw_bytes += n;
   c->st.symbols += h->symbols;
@@ -776,6 +820,7 @@ static int gather_packed(mk_ctx* c, ExportView& v, u64* d_keys_out, u64* d_cnts_
                          bool to_host) {
   int rc;
   size_t rows = 0;
+  const auto t_gather = std::chrono::steady_clock::now();
   if (c->mode == MK_MODE_DENSE) {
     const size_t nbins = c->run_slots;
     std::vector<u64> bins(nbins);
@@ -816,6 +861,8 @@ static int gather_packed(mk_ctx* c, ExportView& v, u64* d_keys_out, u64* d_cnts_
                               (uint64_t*)oc, rows, c->bits * c->k)) != MK_OK) return rc;
       mk_prof_end(c);
       if (to_host) {
+        MK_HIP(hipStreamSynchronize(c->stream));  // (so that sort and copy are timed apart: ~10 us)
+        c->ex_st.s_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gather).count();
         v.pkeys.resize(rows);
         v.pcnts.resize(rows);
         MK_HIP(hipMemcpyAsync(v.pkeys.data(), ok, rows * 8, hipMemcpyDeviceToHost, c->stream));
@@ -867,6 +914,8 @@ static int gather_packed(mk_ctx* c, ExportView& v, u64* d_keys_out, u64* d_cnts_
                                  (uint64_t*)scratch, (uint64_t*)ok, (uint64_t*)oc)) != MK_OK) return rc;
       mk_prof_end(c);
       if (to_host) {
+        MK_HIP(hipStreamSynchronize(c->stream));
+        c->ex_st.s_sort += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_gather).count();
         v.pkeys.resize(2 * rows);
         v.pcnts.resize(rows);
         MK_HIP(hipMemcpyAsync(v.pkeys.data(), ok, 2 * rows * 8, hipMemcpyDeviceToHost, c->stream));
@@ -976,9 +1025,22 @@ static int write_view_tsv(mk_ctx* c, const ExportView& v, const char* path, cons
 static int build_view(mk_ctx* c, ExportView& v) {
   MK_HIP(hipSetDevice(c->device));
   { int rc_ = settle(c); if (rc_) return rc_; }
+  const auto t0 = std::chrono::steady_clock::now();
+  c->ex_st = mk_export_stats_t{};
   int rc = gather_packed(c, v, nullptr, nullptr, 0, nullptr, true);
   if (rc) return rc;
-  return gather_ref(c, v, true);
+  rc = gather_ref(c, v, true);
+  // (s_sort was added up inside; the rest of the gathering is the copies to the host)
+  c->ex_st.s_d2h = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() - c->ex_st.s_sort;
+  c->ex_st.s_total = c->ex_st.s_sort + c->ex_st.s_d2h;
+  c->ex_st.rows = v.packed_rows() + v.rorder.size();
+  return rc;
+}
+
+extern "C" int mk_export_stats(mk_ctx* c, mk_export_stats_t* out) {
+  if (!c || !out) return MK_ERR_ARG;
+  *out = c->ex_st;
+  return MK_OK;
 }
 
 extern "C" int mk_export_size(mk_ctx* c, size_t* rows) {
@@ -1007,11 +1069,14 @@ extern "C" int mk_export(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t row
   if (rows && (!kmers || !counts)) { c->err = "mk_export: NULL output"; return MK_ERR_ARG; }
   const size_t k = (size_t)c->k;
   size_t at = 0;
+  const auto t_f = std::chrono::steady_clock::now();
   merged_rows(c, v, [&](const uint8_t* s, u64 n) {
     memcpy(kmers + at * k, s, k);
     counts[at] = n;
     ++at;
   });
+  c->ex_st.s_format = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f).count();
+  c->ex_st.s_total += c->ex_st.s_format;
   return MK_OK;
 }
 
@@ -1032,8 +1097,17 @@ static int write_view_tsv(mk_ctx* c, const ExportView& v, const char* path, cons
   std::vector<char> out;
   out.reserve(1 << 22);
   const size_t k = (size_t)c->k;
+  const auto t_f = std::chrono::steady_clock::now();
+  double s_write = 0;
+  uint64_t bytes = 0;
   auto flush = [&]() {
-    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+    if (!out.empty()) {
+      const auto tw = std::chrono::steady_clock::now();
+      fwrite(out.data(), 1, out.size(), f);
+      s_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      bytes += out.size();
+      out.clear();
+    }
   };
   const std::string head = std::string("k-mer\t") + basename + "_Count\n";
   out.insert(out.end(), head.begin(), head.end());
@@ -1049,7 +1123,14 @@ static int write_view_tsv(mk_ctx* c, const ExportView& v, const char* path, cons
   });
   flush();
   const bool bad = ferror(f) != 0;
-  if (fclose(f) != 0 || bad) { c->err = std::string("mk_write_tsv: write failed: ") + path; return MK_ERR_IO; }
+  const auto tc = std::chrono::steady_clock::now();
+  const bool bad_close = fclose(f) != 0;
+  s_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc).count();
+  c->ex_st.bytes = bytes;
+  c->ex_st.s_write = s_write;
+  c->ex_st.s_format = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f).count() - s_write;
+  c->ex_st.s_total += c->ex_st.s_format + s_write;
+  if (bad_close || bad) { c->err = std::string("mk_write_tsv: write failed: ") + path; return MK_ERR_IO; }
   return MK_OK;
 }
 
@@ -1287,8 +1368,17 @@ static int write_merged(mk_ctx* const* ctxs, int n, const char* const* names, co
   if (!f) { c->err = std::string("mk_write_merged_tsv: cannot open ") + path; return MK_ERR_IO; }
   std::vector<char> out;
   out.reserve(1 << 22);
+  const auto t_f = std::chrono::steady_clock::now();
+  double s_write = 0;
+  uint64_t bytes = 0;
   auto flush = [&]() {
-    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+    if (!out.empty()) {
+      const auto tw = std::chrono::steady_clock::now();
+      fwrite(out.data(), 1, out.size(), f);
+      s_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      bytes += out.size();
+      out.clear();
+    }
   };
   {
     std::string head = first_column;
@@ -1339,8 +1429,17 @@ extern "C" int mk_write_merged_tsv_t(mk_ctx* const* ctxs, int n, const char* con
   if (!f) { c->err = std::string("mk_write_merged_tsv_t: cannot open ") + path; return MK_ERR_IO; }
   std::vector<char> out;
   out.reserve(1 << 22);
+  const auto t_f = std::chrono::steady_clock::now();
+  double s_write = 0;
+  uint64_t bytes = 0;
   auto flush = [&]() {
-    if (!out.empty()) { fwrite(out.data(), 1, out.size(), f); out.clear(); }
+    if (!out.empty()) {
+      const auto tw = std::chrono::steady_clock::now();
+      fwrite(out.data(), 1, out.size(), f);
+      s_write += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+      bytes += out.size();
+      out.clear();
+    }
   };
   const char* head = "sample";
   out.insert(out.end(), head, head + 6);

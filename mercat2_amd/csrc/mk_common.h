@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <string>
+#include <mutex>
+#include <shared_mutex>
 #include <vector>
 #include "../../include/mercat_hip.h"
 
@@ -65,6 +67,7 @@ struct MkChunkInfo {
   unsigned long long parse_fallback;  // fast parser saw a blank in a sequence line: re-parse generally
   unsigned long long records;       // super-k-mer records written (partitioned nt path)
   unsigned long long part_overflow; // a bucket region sized from a sampled histogram was too small: partition again, exactly
+  unsigned long long spilled;       // fused upsert (mk_skcount.hip): survivors written to the spill list instead of the running table
 };
 
 enum MkMode { MK_MODE_DENSE = 0, MK_MODE_HASH64 = 1, MK_MODE_HASH128 = 2, MK_MODE_BYREF = 3 };
@@ -171,6 +174,17 @@ struct mk_ctx {
   int surv_regions = 0;   // survivors of the last chunk are laid out per bucket (kstart/nsurv in part_meta)
   double nk_hint = 8.0;   // windows per super-k-mer record seen in the previous chunk
   double items_hint = 0;  // records per analysis thread (32 positions) seen in the previous chunk; 0 = not known yet
+  // fused upsert (mk_skcount.hip): the count kernel puts a chunk's survivors into the running table itself
+  int use_fused = 1;                  // MK_NO_FUSE=1 turns it off
+  int fuse_cap = 0;                   // list entries per sweep the NEXT count launch may use (0: survivors go to their regions)
+  bool fused_last = false;            // the last count launch was a fused one
+  unsigned long long surv_hint = 0;   // survivors of the previous chunk of this sample
+  bool surv_hint_ok = false;
+  // one table for several contexts of a device (mk_share_table): the fused launches of this context upsert into the owner's
+  mk_ctx* share_owner = nullptr;
+  std::vector<mk_ctx*> sharers;       // contexts whose fused launches upsert into THIS context's table
+  std::shared_mutex table_mu;         // shared: a launch reads run.p / run_slots; exclusive: the table is replaced (grown) or cleared
+  std::mutex rows_mu;                 // run_rows of an owner is added to by its sharers' host threads
 
   // export scratch
   MkDevBuf ex_keys, ex_cnts, ex_keys2, ex_cnts2, ex_tmp;
@@ -193,6 +207,7 @@ struct mk_ctx {
 
   // stats
   mk_stats_t st{};
+  mk_export_stats_t ex_st{};  // of the last mk_export / mk_write_tsv (mk_export_stats)
   std::vector<MkEventPair> events;
   std::vector<hipEvent_t> event_pool;
 };
@@ -228,6 +243,9 @@ bool mk_part_inherit(mk_ctx* c, size_t seq_len, int p1_log2, uint64_t min_count,
 void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned long long* khist, unsigned long long* start,
                        unsigned* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
                        unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas);
+// mk_skcount.hip: the count kernel of the one-word super-k-mer path over the bucket regions the scatter filled
+int mk_launch_sk_count(mk_ctx* c, const unsigned long long* start, unsigned* cursor, const unsigned long long* kstart,
+                       unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,

@@ -322,6 +322,7 @@ struct Dispatcher : MkCutSink {
   uint64_t min_count = 0;
   size_t reserve = 0;    // raw-buffer bytes to set aside when a chunk is opened
   double s_wait_gpu = 0;
+  double s_feed = 0;     // seconds inside the copy calls (hipMemcpyAsync out of the pinned ring, raw-buffer growth)
   std::vector<int> touched;  // lanes that received bytes of the block being processed
   int rc_lane = -1;
 
@@ -361,7 +362,10 @@ struct Dispatcher : MkCutSink {
     if (cur < 0 && (rc = open_chunk())) return rc;
     mk_ctx* c = (*lanes)[cur].c;
     const bool pinned = p >= ring->mem && p < ring->mem + (size_t)ring->slots * ring->block;
-    if ((rc = mk_feed_host_async(c, p, n, /*wait=*/!pinned))) { rc_lane = cur; return rc; }
+    const auto t0 = Clock::now();
+    rc = mk_feed_host_async(c, p, n, /*wait=*/!pinned);
+    s_feed += seconds_since(t0);
+    if (rc) { rc_lane = cur; return rc; }
     if (pinned && (touched.empty() || touched.back() != cur)) touched.push_back(cur);
     return MK_OK;
   }
@@ -535,9 +539,12 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
   D.reserve = reserve;
   MkCutScanner scan(chunked ? chunk_bytes : (split ? piece_bytes : UINT64_MAX), &D, /*record_starts_only=*/split);
   uint64_t text_bytes = 0;
-  double s_wait_io = 0;
+  double s_wait_io = 0, s_block = 0, s_retire = 0;
+  const double s_setup = seconds_since(t_begin);
   const uint64_t lag = (uint64_t)R.slots / 2;
   auto retire = [&](uint64_t i) {  // wait for the copies out of block i, then let the readers have its slot
+    const auto t0 = Clock::now();
+    struct Acc { double& a; Clock::time_point t; ~Acc() { a += seconds_since(t); } } acc{s_retire, t0};
     for (int j = 0; j < lanes_n; ++j) {
       const size_t e = (size_t)(i % (uint64_t)R.slots) * lanes_n + j;
       if (ev_set[e]) { (void)hipEventSynchronize(events[e]); ev_set[e] = 0; }
@@ -554,7 +561,10 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     const int s = (int)(i % (uint64_t)R.slots);
     const size_t n = R.len[s];
     D.touched.clear();
-    if ((rc = scan.block(R.at(i), n, R.has_cr[s] != 0)) != MK_OK) break;
+    const auto tb = Clock::now();
+    rc = scan.block(R.at(i), n, R.has_cr[s] != 0);
+    s_block += seconds_since(tb);
+    if (rc != MK_OK) break;
     text_bytes += n;
     for (int j : D.touched) {
       const size_t e = (size_t)s * lanes_n + j;
@@ -563,6 +573,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     }
     if (i >= lag) retire(i - lag);
   }
+  const auto t_drain = Clock::now();
   if (rc == MK_OK) rc = scan.finish();
   if (rc == MK_OK && D.cur < 0 && D.chunks == 0) rc = D.open_chunk();  // an empty file is one empty chunk
   if (rc == MK_OK) rc = D.close_chunk();
@@ -596,6 +607,7 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     else if (D.rc_lane > 0) c0->err = ctxs[D.rc_lane]->err;
     return rc;
   }
+  const double s_drain = seconds_since(t_drain);
   // the sample's table ends up in ctxs[0]: the contexts of one GPU are summed on that GPU into the first of them,
   // then the GPUs' tables are summed into ctxs[0] (peer copies, mk_multi.hip)
   const auto t_merge = Clock::now();
@@ -628,6 +640,11 @@ extern "C" int mk_count_file(mk_ctx* const* ctxs, int nctx, const char* path, ui
     st->s_wait_io = s_wait_io;
     st->s_wait_gpu = D.s_wait_gpu;
     st->s_total = seconds_since(t_begin);
+    st->s_setup = s_setup;
+    st->s_feed = D.s_feed;
+    st->s_scan = s_block - D.s_feed - D.s_wait_gpu;  // (the dispatcher's own work on the text: the Chunker rule)
+    st->s_retire = s_retire;
+    st->s_drain = s_drain;
   }
   return MK_OK;
 }

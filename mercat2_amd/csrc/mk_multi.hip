@@ -15,10 +15,12 @@
 #include "mk_common.h"
 #include "mk_device.h"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -260,6 +262,55 @@ static int sample_keys(mk_ctx* c, size_t stride, std::vector<u64>& out) {
   return MK_OK;
 }
 
+// ---- RCCL as the transport of the exchange (MK_MERGE_RCCL): grouped ncclSend / ncclRecv of the owner segments, straight
+// between peers over xGMI -- the collective SURVEY 8(e) names, behind the C ABI.  The library is opened when the flag is
+// first used (dlopen: a box without RCCL still loads this library and keeps the peer-copy transport); one communicator
+// per distinct device, made once per device list with ncclCommInitAll (one process, all GPUs) and kept.
+struct Rccl {
+  typedef void* comm_t;
+  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string why;  // why it is not available
+  std::vector<std::pair<std::vector<int>, std::vector<comm_t>>> comms;  // per device list
+  bool ok() const { return CommInitAll != nullptr; }
+  static Rccl& get() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    void* h = nullptr;
+    const char* env = getenv("MK_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names)
+      if (nm && (h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) { r.why = std::string("librccl.so not found (") + (dlerror() ? dlerror() : "dlopen failed") + ")"; return r; }
+    auto sym = [&](const char* nm) { void* p = dlsym(h, nm); if (!p) r.why = std::string("librccl.so lacks ") + nm; return p; };
+    void* f[6] = {sym("ncclCommInitAll"), sym("ncclGroupStart"), sym("ncclGroupEnd"), sym("ncclSend"), sym("ncclRecv"), sym("ncclGetErrorString")};
+    for (void* p : f) if (!p) return r;
+    r.GroupStart = (int (*)())f[1];
+    r.GroupEnd = (int (*)())f[2];
+    r.Send = (int (*)(const void*, size_t, int, int, comm_t, hipStream_t))f[3];
+    r.Recv = (int (*)(void*, size_t, int, int, comm_t, hipStream_t))f[4];
+    r.GetErrorString = (const char* (*)(int))f[5];
+    r.CommInitAll = (int (*)(comm_t*, int, const int*))f[0];
+    return r;
+  }
+  // communicators for these devices (rank r = devs[r]); nullptr + why on failure
+  const std::vector<comm_t>* comms_for(const std::vector<int>& devs) {
+    for (auto& e : comms) if (e.first == devs) return &e.second;
+    std::vector<comm_t> cs(devs.size(), nullptr);
+    const int rc = CommInitAll(cs.data(), (int)devs.size(), devs.data());
+    if (rc != 0) { why = std::string("ncclCommInitAll: ") + GetErrorString(rc); return nullptr; }
+    comms.emplace_back(devs, cs);
+    return &comms.back().second;
+  }
+};
+#define MK_NCCL_UINT64 5  /* ncclUint64 (rccl.h: ncclDataType_t) */
+
 // direct access between two devices, both ways; 1 = direct (xGMI / PCIe P2P), 0 = hipMemcpyPeer stages the bytes itself
 static int enable_peer_pair(int a, int b) {
   if (a == b) return 1;
@@ -403,6 +454,13 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
       if (ctxs[j] == c) { c0->err = "mk_merge_devices: the same context twice"; return MK_ERR_ARG; }
   }
   std::lock_guard<std::mutex> merge_lock(g_merge_mu);
+  // (the phases below set the calling thread's device context by context: put the caller's back on every way out --
+  // the same process may drive torch on another device)
+  struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = -1; } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+  } device_guard;
   const auto t_begin = Clock::now();
   const bool gather = (flags & MK_MERGE_GATHER) != 0;
   const int m = gather ? 1 : n;  // owners
@@ -440,7 +498,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
       // host sorts a few thousand values only
       const size_t stride = std::max<size_t>(1, total / (512 * (size_t)m));
       std::vector<std::vector<u64>> parts((size_t)n);
-      int bad = -1;
+      std::atomic<int> bad{-1};
       rc = on_every(n, [&](int i) { int r = sample_keys(ctxs[i], stride, parts[i]); if (r) bad = i; return r; });
       if (rc) return fail(bad, rc);
       std::vector<u64> all;
@@ -460,7 +518,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   const double s_bounds = secs(t_begin);
   const auto t_a = Clock::now();
   {
-    int bad = -1;
+    std::atomic<int> bad{-1};
     rc = on_every(n, [&](int i) {
       mk_ctx* c = ctxs[i];
       int r;
@@ -504,7 +562,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
       recv[j] += counts[i][j];
     }
   {
-    int bad = -1;
+    std::atomic<int> bad{-1};
     rc = on_every(n, [&](int i) {
       mk_ctx* c = ctxs[i];
       int r;
@@ -525,6 +583,73 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
   std::vector<hipEvent_t> sent((size_t)n, nullptr);
   auto drop_events = [&] { for (auto& e : sent) if (e) { (void)hipEventDestroy(e); e = nullptr; } };
   std::vector<char> sends((size_t)n, 0);
+  const std::vector<Rccl::comm_t>* comms = nullptr;
+  std::vector<int> dev_rank((size_t)n, 0);  // rank of a context's device among the distinct devices
+  if (flags & MK_MERGE_RCCL) {
+    std::vector<int> devs;
+    for (int i = 0; i < n; ++i) {
+      auto it = std::find(devs.begin(), devs.end(), ctxs[i]->device);
+      dev_rank[i] = (int)(it - devs.begin());
+      if (it == devs.end()) devs.push_back(ctxs[i]->device);
+    }
+    Rccl& R = Rccl::get();
+    if (R.ok()) comms = R.comms_for(devs);
+    if (!comms) { c0->err = "mk_merge_devices(MK_MERGE_RCCL): " + R.why; return MK_ERR_UNSUPPORTED; }
+    S.rccl = 1;
+  }
+  if (comms) {
+    // Round s: source i sends its segment for owner (i + s) mod n -- with one context per GPU every rank has one send and
+    // one receive per round, the usual all-to-all schedule, all of a round's in ONE group: ncclSend on the source's
+    // stream, ncclRecv on the owner's (the owner's import, queued on that stream behind it, needs no event).  Segments
+    // between two contexts of ONE device (the one-GPU rehearsal; the product sums a GPU's contexts before it merges
+    // GPUs) are a send of that device's rank to itself, each in a group of its own: several self-sends in one group
+    // lost rows on RCCL 2.x here.
+    Rccl& R = Rccl::get();
+    int nrc = 0;
+    auto post = [&](int i, int j) {
+      mk_ctx* src = ctxs[i];
+      mk_ctx* dst = ctxs[j];
+      u64 seg = 0;
+      for (int q = 0; q < j; ++q) seg += counts[i][q];
+      const size_t words = (size_t)counts[i][j] * rw;
+      const u64* from = (const u64*)src->xfer_out.p + seg * (u64)rw;
+      u64* to = (u64*)dst->xfer_in.p + recv_off[i][j] * (u64)rw;
+      if (hipSetDevice(src->device) != hipSuccess) return -1;
+      int r = R.Send(from, words, MK_NCCL_UINT64, dev_rank[j], (*comms)[(size_t)dev_rank[i]], src->stream);
+      if (r) return r;
+      if (hipSetDevice(dst->device) != hipSuccess) return -1;
+      r = R.Recv(to, words, MK_NCCL_UINT64, dev_rank[i], (*comms)[(size_t)dev_rank[j]], dst->stream);
+      sends[i] = 1;
+      S.rows_moved += counts[i][j];
+      S.bytes_moved += words * sizeof(u64);
+      return r;
+    };
+    for (int s = 1; s < n && nrc == 0; ++s) {
+      bool any = false;
+      for (int i = 0; i < n; ++i) {
+        const int j = (i + s) % n;
+        any = any || (j < m && counts[i][j] && ctxs[i]->device != ctxs[j]->device);
+      }
+      if (any) {
+        nrc = R.GroupStart();
+        for (int i = 0; i < n && nrc == 0; ++i) {
+          const int j = (i + s) % n;
+          if (j < m && counts[i][j] && ctxs[i]->device != ctxs[j]->device) nrc = post(i, j);
+        }
+        const int erc = R.GroupEnd();
+        if (nrc == 0) nrc = erc;
+      }
+      for (int i = 0; i < n && nrc == 0; ++i) {
+        const int j = (i + s) % n;
+        if (!(j < m && counts[i][j] && ctxs[i]->device == ctxs[j]->device)) continue;
+        nrc = R.GroupStart();
+        if (nrc == 0) nrc = post(i, j);
+        const int erc = R.GroupEnd();
+        if (nrc == 0) nrc = erc;
+      }
+    }
+    if (nrc != 0) { c0->err = std::string("RCCL exchange of table rows: ") + (nrc > 0 ? R.GetErrorString(nrc) : "hipSetDevice failed"); rc = MK_ERR_HIP; }
+  } else
   {
     std::vector<std::pair<int, int>> pairs_seen;
     for (int s = 1; s < n && rc == MK_OK; ++s)
@@ -578,7 +703,7 @@ extern "C" int mk_merge_devices(mk_ctx* const* ctxs, int n, int flags, mk_merge_
 
   // ---- phase D: every owner insert-adds its own segment and what arrived; text rows into ctxs[0]
   {
-    int bad = -1;
+    std::atomic<int> bad{-1};
     rc = on_every(n, [&](int j) {
       mk_ctx* c = ctxs[j];
       int r;

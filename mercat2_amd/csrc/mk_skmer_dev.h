@@ -74,7 +74,7 @@ __device__ __forceinline__ unsigned sk_reserve8(const unsigned (&count)[8], SkCu
         "s_mov_b64 exec, %1"
         : "+v"(r[i]), "=&s"(saved)
         : "v"(voff4), "v"(count[i]), "s"(cursor + i * THREADS)
-        : "memory", "vcc");
+        : "memory", "vcc", "scc");  // s_and_saveexec writes SCC
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -220,4 +220,13 @@ __device__ __forceinline__ unsigned sk_cut_starts(unsigned starts, unsigned vali
   for (unsigned c = (starts << nkmax) & a; c; c = (c << nkmax) & a) s2 |= c;
   return s2;
 }
+
+// in-kernel phase stamps of -DMK_STAMP builds (wave 0 of a workgroup; s_memtime ticks)
+#ifdef MK_STAMP
+#define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
+#define STAMP_ADD(acc, t0) { unsigned long long t1__; STAMP(t1__); acc += t1__ - t0; t0 = t1__; }
+#else
+#define STAMP(var)
+#define STAMP_ADD(acc, t0)
+#endif
 

@@ -219,6 +219,11 @@ __device__ __forceinline__ u64 home128(u64 hi, u64 lo, u64 mask) { return mk_mix
 // release store / acquire fence at agent scope would do the same job with `buffer_wbl2 sc1` / `buffer_inv sc1` -- a
 // write-back and an invalidation of the XCD's whole L2 -- per NEW ROW and per probe: measured on 2.1 M new rows
 // (protein 13-mers, tools/aa128_probe.py) 5.3 ms against 0.6 ms for the merge kernel.
+// The fast form leans on two gfx9-family facts: stores are counted in vmcnt (gfx10+ counts them in vscnt, which this wait
+// would not cover) and sc1 accesses are served at the device's point of coherence.  Any other target takes the C++ form.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__) && !defined(MK_UPSERT128_FENCES)
+#define MK_UPSERT128_FENCES 1
+#endif
 #ifdef MK_UPSERT128_FENCES  // (A/B builds: the C++ memory-order form)
 #define MK_PUBLISH128(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
 #define MK_ACQUIRE128() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")

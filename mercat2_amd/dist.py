@@ -25,6 +25,10 @@ import torch.distributed as dist
 
 _SIGN = -(1 << 63)
 
+# figures of this rank's last merge_ranks call (for bench.py's per-rank lines): rows and bytes that left for / arrived
+# from OTHER ranks, and the wall seconds of the three phases
+LAST_MERGE: dict = {}
+
 
 def _ordered(keys: torch.Tensor) -> torch.Tensor:
     """uint64 keys stored in int64 tensors: flip the sign bit so signed order == unsigned order."""
@@ -114,12 +118,16 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
     (mk_bucket_rows_device: interleaved {key word(s), count} rows, owner after owner -- no sort, no torch.cat), sent
     with one all_to_all_single, and insert-added at the owner (mk_import_rows_device).  ``balanced``: owner bounds
     from sampled keys instead of equal key ranges.  Dense tables (k * bits <= 15) are ONE reduce of the bins to rank 0."""
+    import time
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1 and not always:
         if min_count > 1:
             ctx.filter_min(min_count)
         return ctx.rows()
+    t_begin = time.perf_counter()
+    t_bucket = t_wire = t_begin
+    wire_out = wire_in = rows_out = rows_in = 0
     dev = device if device is not None else torch.device("cuda", ctx.device)
     staged = dev.type != "cpu" and dist.get_backend(group) == "gloo"  # gloo moves host memory (test / rehearsal path)
     mode = ctx.stats()["mode_name"]
@@ -148,6 +156,7 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
         cap = ctx.rows() + 1
         rows = torch.empty((cap, words + 1), dtype=torch.int64, device=dev)
         send_l = ctx.bucket_rows_device(bounds, rows.data_ptr(), cap) if packed else [0] * world
+        t_bucket = time.perf_counter()
         meta_dev = torch.device("cpu") if staged else dev
         meta = torch.tensor([[n, int(ex_c.size)] for n in send_l], dtype=torch.int64, device=meta_dev)
         got_meta = torch.empty_like(meta)
@@ -166,6 +175,10 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
             dist.all_to_all_single(out, rows[:n_send], recv_l, send_l, group=group)
         if n_recv:
             _wait_current_stream(dev)  # the rows have arrived before the engine's own stream reads them
+        t_wire = time.perf_counter()
+        rows_out, rows_in = n_send - int(send_l[rank]), n_recv - int(recv_l[rank])
+        wire_out, wire_in = rows_out * 8 * (words + 1), rows_in * 8 * (words + 1)
+        if n_recv:
             ctx.import_rows_device(out.data_ptr(), n_recv)
     # rows kept as text: gathered (as objects, through the host) to rank 0 only when some rank has any
     if any(extras):
@@ -180,7 +193,13 @@ def merge_ranks(ctx, key_bits: int, group=None, device=None, min_count: int = 0,
                 ctx.import_exotic(k_arr, c_arr)
     if min_count > 1:
         ctx.filter_min(min_count)
-    return ctx.rows()
+    owned = ctx.rows()
+    t_end = time.perf_counter()
+    LAST_MERGE.clear()
+    LAST_MERGE.update(rows_sent=rows_out, rows_received=rows_in, wire_bytes_sent=wire_out, wire_bytes_received=wire_in,
+                      bucket_s=t_bucket - t_begin, collectives_s=max(0.0, t_wire - t_bucket), import_s=max(0.0, t_end - t_wire),
+                      total_s=t_end - t_begin, rows_owned=owned)
+    return owned
 
 
 def _wait_current_stream(dev) -> None:

@@ -105,8 +105,10 @@ def _sum_into_first(ctxs: Sequence[native.Counter]) -> None:
         native.merge_devices(leaders, native.MERGE_GATHER)
 
 
-def _finish(ctx: native.Counter, basename: str, out_file, report=print) -> Tuple[str, Optional[os.PathLike]]:
+def _finish(ctx: native.Counter, basename: str, out_file, report=print, timings: Optional[dict] = None) -> Tuple[str, Optional[os.PathLike]]:
     rows = ctx.write_tsv(out_file, basename)
+    if timings is not None:
+        timings["export"] = ctx.export_stats()
     if rows:
         report(f"Significant k-mers: {rows}")
         return basename, out_file
@@ -284,7 +286,7 @@ def run_sample(basename: str, file, out_file, kmer: int, min_count: int, chunk_m
         if stats is not None:
             stats.update(st)
         t1 = timeit.default_timer()
-        result = _finish(ctxs[0], basename, out_file, report)
+        result = _finish(ctxs[0], basename, out_file, report, timings)
         if timings is not None:
             timings.update(count_s=t1 - t0, tsv_s=timeit.default_timer() - t1, chunks=st["chunks"], contexts=st["contexts"],
                            devices=st["devices"], merge_s=st["s_merge"], wait_io_s=st["s_wait_io"], split_pieces=st["split_pieces"])

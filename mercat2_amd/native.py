@@ -32,9 +32,10 @@ ABI_SYMBOLS = [
     "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
     "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
     "mk_device_count", "mk_reset_for", "mk_textwrap", "mk_set_clean", "mk_clean_stats", "mk_clean_runs",
+    "mk_export_stats",
 ]
-MK_ABI = 3  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
-MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED = 0, 1, 2
+MK_ABI = 4  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
+MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED, MERGE_RCCL = 0, 1, 2, 4
 
 
 class MercatHipError(RuntimeError):
@@ -59,7 +60,7 @@ class Stats(C.Structure):
                [(n, C.c_double) for n in ("ms_parse", "ms_pack", "ms_count", "ms_exotic", "ms_filter", "ms_export")] + \
                [(n, C.c_uint64) for n in ("n_parse", "n_pack", "n_count", "n_exotic", "n_filter", "n_export")] + \
                [("ms_part", C.c_double), ("n_part", C.c_uint64), ("records", C.c_uint64), ("distinct", C.c_uint64),
-                ("part_retries", C.c_uint64), ("part_reused", C.c_uint64)]
+                ("part_retries", C.c_uint64), ("part_reused", C.c_uint64), ("fused_chunks", C.c_uint64), ("fuse_spilled", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -69,10 +70,20 @@ class FileStats(C.Structure):
     """mk_file_stats_t (include/mercat_hip.h)."""
     _fields_ = ([(n, C.c_uint64) for n in ("disk_bytes", "text_bytes", "chunks")] +
                 [(n, C.c_int32) for n in ("gz", "chunked", "members", "threads", "contexts", "devices", "split_pieces", "pad_")] +
-                [(n, C.c_double) for n in ("s_wait_io", "s_wait_gpu", "s_total", "s_merge")])
+                [(n, C.c_double) for n in ("s_wait_io", "s_wait_gpu", "s_total", "s_merge",
+                                           "s_setup", "s_scan", "s_feed", "s_retire", "s_drain")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "pad_"}
+
+
+class ExportStats(C.Structure):
+    """mk_export_stats_t (include/mercat_hip.h)."""
+    _fields_ = ([(n, C.c_uint64) for n in ("rows", "bytes")] +
+                [(n, C.c_double) for n in ("s_sort", "s_d2h", "s_format", "s_write", "s_total")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class CleanGpu(C.Structure):
@@ -83,7 +94,7 @@ class CleanGpu(C.Structure):
 class MergeStats(C.Structure):
     """mk_merge_stats_t (include/mercat_hip.h)."""
     _fields_ = ([(n, C.c_uint64) for n in ("rows_in", "rows_out", "rows_moved", "bytes_moved", "max_owned")] +
-                [(n, C.c_int32) for n in ("contexts", "devices", "peer_direct", "pad_")] +
+                [(n, C.c_int32) for n in ("contexts", "devices", "peer_direct", "rccl")] +
                 [(n, C.c_double) for n in ("s_bucket", "s_copy", "s_import", "s_total")])
 
     def as_dict(self):
@@ -138,6 +149,7 @@ def lib() -> C.CDLL:
         "mk_export_size": (C.c_int, [vp, szp]),
         "mk_export": (C.c_int, [vp, u8p, u64p, C.c_size_t]),
         "mk_write_tsv": (C.c_int, [vp, C.c_char_p, C.c_char_p, szp]),
+        "mk_export_stats": (C.c_int, [vp, C.POINTER(ExportStats)]),
         "mk_export_pairs_device": (C.c_int, [vp, u64p, u64p, C.c_size_t, szp]),
         "mk_import_pairs_device": (C.c_int, [vp, u64p, u64p, C.c_size_t]),
         "mk_export_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t, szp]),
@@ -587,6 +599,12 @@ class Counter:
         n = C.c_size_t(0)
         self._check(self._L.mk_write_tsv(self._h, os.fsencode(str(path)), basename.encode(), C.byref(n)))
         return n.value
+
+    def export_stats(self) -> dict:
+        """Where the last export / write_tsv of this context spent its time (mk_export_stats)."""
+        st = ExportStats()
+        self._check(self._L.mk_export_stats(self._h, C.byref(st)))
+        return st.as_dict()
 
     # -- multi-GPU plumbing (device pointers come from torch tensors)
     def export_pairs_device(self, keys_ptr: int, counts_ptr: int, cap: int) -> int:

@@ -3,7 +3,7 @@
 
 Run only in the build container (needs /root/reference and ~40 GB of RAM, 15-30 minutes on 8 cores):
 
-    python tests/golden/make_s2_golden.py [--procs 5] [--only s2|s3]
+    python tests/golden/make_s2_golden.py [--procs 5] [--only s2|s3|s1|s3full]
 
 What it does (bin/mercat2.py:86-106,115-137 composed by hand, since bin/mercat2.py needs Ray):
   S2  10,000,000 reads x 150 bp from a 10 Mbp genome (seeds 3/4: bench.py's own generator, mk_synth_reads)
@@ -15,6 +15,10 @@ What it does (bin/mercat2.py:86-106,115-137 composed by hand, since bin/mercat2.
       find_kmers(chunk, 31, 10) is called directly on the last chunk and compared with the filter above.
   S3  the first two Chunker chunks of the 50 M-read sample (G = 50 Mbp, seeds 6/7), k = 63, -c 2:
       the two-word table at tens of millions of rows.
+  S1  (round 4) BASELINE config 2: 1,000,000 reads x 150 bp from a 1 Mbp genome (seeds 1/2), k = 21, -c 10 -s 100
+      (159 MB of text: 2 chunks).
+  S3full (round 4) BASELINE config 5 whole: 50,000,000 reads (G = 50 Mbp, seeds 6/7), k = 63, -c 10 -s 100: all 78 Chunker
+      chunks through the REFERENCE find_kmers(chunk, 63, 10) (~10 GB of dict per process: --procs 4, ~75 minutes).
 Recorded per table: rows, sum, sha256 of the TSV text ("k-mer\t{base}_Count\n" + sorted rows), sha256 of the
 concatenated keys and of the little-endian u64 counts; plus the chunk offsets.  Nothing of the reference's
 source is stored.
@@ -50,6 +54,10 @@ def count_chunk(args):
     path, k, c, want_canonical, check_direct = args
     kmers = load("ref_kmers", "lib/mercat2_kmers.py")
     t0 = time.time()
+    if check_direct == "only":  # the reference's own filter, nothing else (the big samples: no second dict)
+        fwd = kmers.find_kmers(Path(path), k, c)
+        os.unlink(path)  # (the chunk file is not needed again: keep the disk use of an 8 GB sample bounded)
+        return fwd, None, {"path": os.path.basename(path), "survivors": len(fwd), "seconds": round(time.time() - t0, 1)}
     raw = kmers.find_kmers(Path(path), k, 1)
     fwd = {key: n for key, n in raw.items() if n >= c}
     if check_direct:
@@ -85,7 +93,7 @@ def digest(base, table):
             "counts_sha256": hashlib.sha256(counts.tobytes()).hexdigest(), "max_count": int(counts.max()) if len(keys) else 0}
 
 
-def run_sample(tag, base, genome, gseed, reads, rseed, k, c, procs, want_canonical, first_chunks, tmp):
+def run_sample(tag, base, genome, gseed, reads, rseed, k, c, procs, want_canonical, first_chunks, tmp, direct_only=False):
     from mercat2_amd import native
     from mercat2_amd.chunker import chunk_offsets
     chunker = load("ref_chunker", "lib/mercat2_Chunker.py")
@@ -109,7 +117,9 @@ def run_sample(tag, base, genome, gseed, reads, rseed, k, c, procs, want_canonic
     if first_chunks:
         files = files[:first_chunks]
     print(tag, "chunks", len(files), "of", len(offs) - 1, flush=True)
-    jobs = [(p, k, c, want_canonical, i == len(files) - 1 and not first_chunks) for i, p in enumerate(files)]
+    jobs = [(p, k, c, want_canonical, "only" if direct_only else (i == len(files) - 1 and not first_chunks)) for i, p in enumerate(files)]
+    if direct_only:
+        os.unlink(fna)
     fwd_total, can_total, infos = {}, {}, []
     with mp.get_context("fork").Pool(procs, maxtasksperchild=1) as pool:
         for fwd, can, info in pool.imap(count_chunk, jobs):
@@ -132,7 +142,7 @@ def run_sample(tag, base, genome, gseed, reads, rseed, k, c, procs, want_canonic
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--procs", type=int, default=5)
-    ap.add_argument("--only", choices=("s2", "s3"), default=None)
+    ap.add_argument("--only", choices=("s2", "s3", "s1", "s3full"), default=None)
     ap.add_argument("--tmp", default="/tmp/mk_s2_golden")
     args = ap.parse_args()
     if not REF.is_dir():
@@ -146,6 +156,12 @@ def main():
         # 1.4 M reads hold the first two 100 MiB chunks of S3 (a read is ~161 bytes of text); the third "chunk" here is
         # the cut-off remainder and is not used
         res["S3head|k63|c2|s100|chunks2"] = run_sample("s3", "S3", 50_000_000, 6, 1_400_000, 7, 63, 2, min(args.procs, 2), False, 2, args.tmp)
+        dst.write_text(json.dumps(res, indent=1, sort_keys=True))
+    if args.only == "s1":
+        res["S1|k21|c10|s100"] = run_sample("s1", "S1", 1_000_000, 1, 1_000_000, 2, 21, 10, min(args.procs, 2), False, 0, args.tmp)
+        dst.write_text(json.dumps(res, indent=1, sort_keys=True))
+    if args.only == "s3full":
+        res["S3|k63|c10|s100"] = run_sample("s3full", "S3", 50_000_000, 6, 50_000_000, 7, 63, 10, min(args.procs, 4), False, 0, args.tmp, direct_only=True)
         dst.write_text(json.dumps(res, indent=1, sort_keys=True))
     print(json.dumps({k: {m: v[m]["rows"] for m in ("forward", "canonical") if m in v} for k, v in res.items()}))
 

@@ -100,6 +100,30 @@ def test_s2_canonical_table_is_the_folded_reference_table(s2, tmp_path):
         _check_arrays(*ctx.export(), want)
 
 
+def test_s1_config2_table_is_the_reference_table(tmp_path):
+    """BASELINE config 2 at full size (S1: 1 M x 150 bp from a 1 Mbp genome, k = 21, -c 10 -s 100: two chunks), one and
+    two contexts: the reference's table by sha256."""
+    g = _golden("S1|k21|c10|s100")
+    data = native.synth_reads(g["genome"], g["genome_seed"], g["reads"], g["read_len"], g["read_seed"])
+    offs = [int(x) for x in chunk_offsets(data, g["chunk_mib"] << 20)]
+    assert offs == g["offsets"] and len(offs) == 3
+    view = memoryview(data)
+    want = g["forward"]
+    with native.Counter(g["k"], native.ALPHABET_NT2) as ctx, native.Counter(g["k"], native.ALPHABET_NT2) as other:
+        for lo, hi in zip(offs[:-1], offs[1:]):
+            ctx.count_chunk(view[lo:hi], g["c"])
+        out = tmp_path / "S1_counts.tsv"
+        assert ctx.write_tsv(out, g["basename"]) == want["rows"]
+        assert _sha_file(out) == want["sha256"]
+        _check_arrays(*ctx.export(), want)
+        # chunk 0 in one context, chunk 1 in another, summed on the device (what bench.py's config 2 leg does)
+        ctx.reset()
+        ctx.count_chunk(view[offs[0]:offs[1]], g["c"])
+        other.count_chunk(view[offs[1]:offs[2]], g["c"])
+        ctx.merge_from(other)
+        _check_arrays(*ctx.export(), want)
+
+
 def test_s3_first_chunks_two_word_table_is_the_reference_table(tmp_path):
     g = _golden("S3head|k63|c2|s100|chunks2")
     data = native.synth_reads(g["genome"], g["genome_seed"], g["reads"], g["read_len"], g["read_seed"])

@@ -45,7 +45,10 @@ def _as_dict(kmers, counts, k):
 @pytest.mark.parametrize("k,c,alphabet", [(31, 2, native.ALPHABET_NT2), (21, 1, native.ALPHABET_NT2), (32, 2, native.ALPHABET_NT2),
                                           (33, 2, native.ALPHABET_NT2), (63, 1, native.ALPHABET_NT2), (3, 10, native.ALPHABET_NT2),
                                           (12, 2, native.ALPHABET_NT2), (70, 2, native.ALPHABET_NT2)])
-@pytest.mark.parametrize("n,flags", [(2, native.MERGE_RANGES), (3, native.MERGE_RANGES | native.MERGE_BALANCED), (3, native.MERGE_GATHER)])
+@pytest.mark.parametrize("n,flags", [(2, native.MERGE_RANGES), (3, native.MERGE_RANGES | native.MERGE_BALANCED), (3, native.MERGE_GATHER),
+                                     # the same exchange over RCCL (ncclSend / ncclRecv in one group; the contexts share the one
+                                     # device here, so every segment is a send of rank 0 to itself)
+                                     (3, native.MERGE_RANGES | native.MERGE_BALANCED | native.MERGE_RCCL), (2, native.MERGE_GATHER | native.MERGE_RCCL)])
 def test_merge_devices_equals_the_oracle(k, c, alphabet, n, flags):
     data = _data()
     want = _oracle_chunked(data, k, c)
@@ -58,6 +61,7 @@ def test_merge_devices_equals_the_oracle(k, c, alphabet, n, flags):
         rows_each = [x.rows() for x in ctxs]
         st = native.merge_devices(ctxs, flags)
         assert st["contexts"] == n and st["devices"] == 1
+        assert st["rccl"] == (1 if flags & native.MERGE_RCCL else 0)
         kmers, counts = native.export_multi(ctxs)
         assert _as_dict(kmers, counts, k) == want
         assert native.rows_multi(ctxs) == len(want)

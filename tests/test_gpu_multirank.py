@@ -201,6 +201,16 @@ def test_bench_launches_ranks_and_strong_rows_match(tmp_path):
     assert two["config"]["chunks"] >= 3
     assert two["rows"] == one["rows"] > 0
     assert two["also"]["scaling"] == "weak" and two["also"]["rows"] >= one["rows"]
+    # per-rank phases and wire bytes of the timed region, one entry per rank
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1]
+    assert all(r["count_ms"] > 0 and r["merge_ms"] > 0 and r["wire_bytes_sent"] > 0 for r in two["per_rank"])
+    assert sum(r["rows_owned"] for r in two["per_rank"]) == one["rows"]
+    # ... and the product's one-process path, timed in a fresh child after the ranks: both transports
+    sp = two["also_single_process"]
+    for transport in ("peer_copies", "rccl"):
+        assert "error" not in sp[transport], sp[transport]
+        assert sp[transport]["rows"] == one["rows"] and sp[transport]["n_gpus"] == 2
+        assert sp[transport]["merge_devices"]["rccl"] == (1 if transport == "rccl" else 0)
 
 
 def test_bench_single_process_drives_several_gpus(tmp_path):

@@ -679,6 +679,17 @@ def test_full_size_properties_config5(tmp_path):
         kmers, counts = ctx.export()
     assert st["chunked"] == 1 and st["chunks"] == 78 and st["text_bytes"] == nbytes
     assert stats["windows"] == reads * (150 - k + 1) and stats["exotic_windows"] == 0 and stats["mode_name"] == "hash128"
+    # (round 4) the table itself is pinned: the reference's Chunker + find_kmers(chunk, 63, 10) over all 78 chunks
+    # (tests/golden/make_s2_golden.py --only s3full) -> rows, sum, sha256 of keys and counts
+    import hashlib
+    import json
+    from conftest import GOLDEN
+    gold = json.loads((GOLDEN / "expected_s2.json").read_text()).get("S3|k63|c10|s100")
+    if gold is not None:
+        want = gold["forward"]
+        assert gold["chunks_total"] == 78 and kmers.shape[0] == want["rows"] and int(counts.sum()) == want["sum"]
+        assert hashlib.sha256(np.ascontiguousarray(kmers).tobytes()).hexdigest() == want["keys_sha256"]
+        assert hashlib.sha256(counts.astype("<u8").tobytes()).hexdigest() == want["counts_sha256"]
     keys = kmers.view("S%d" % k).reshape(-1)
     assert np.all(keys[:-1] < keys[1:]) and np.all(counts >= 10)
     assert free0 - free1 < 6 * (1 << 30) < nbytes  # working set of a 100 MiB chunk, not of the 8 GB sample

@@ -108,7 +108,7 @@ def _c_struct_fields(name):
 
 
 @pytest.mark.parametrize("cname,cls", [("mk_merge_stats_t", "MergeStats"), ("mk_file_stats_t", "FileStats"), ("mk_stats_t", "Stats"),
-                                       ("mk_clean_stats_t", "CleanStats"), ("mk_alpha_t", "AlphaStats")])
+                                       ("mk_clean_stats_t", "CleanStats"), ("mk_alpha_t", "AlphaStats"), ("mk_export_stats_t", "ExportStats")])
 def test_struct_layouts_match_the_header(cname, cls):
     ctype = {"uint64_t": C.c_uint64, "int64_t": C.c_int64, "int32_t": C.c_int32, "double": C.c_double}
     want = _c_struct_fields(cname)

@@ -1,10 +1,10 @@
 #!/bin/bash
-# usage: tools/build_variant.sh <tag> "<extra hipcc flags>" [file.hip ...]   (default file: mk_skmer.hip)
+# usage: tools/build_variant.sh <tag> "<extra hipcc flags>" [file.hip ...]   (default file: mk_skcount.hip, the count kernels)
 # Builds build/libmercat_<tag>.so: the named sources recompiled with the extra flags, every other object as in
 # the product build.  For A/B runs on the GPU box: MERCAT_HIP_LIB=$PWD/build/libmercat_<tag>.so python bench.py ...
 set -e
 tag=$1; flags=$2; shift 2 || true
-files=${@:-mk_skmer.hip}
+files=${@:-mk_skcount.hip}
 cd "$(dirname "$0")/../mercat2_amd/csrc"
 make -s -j8 >/dev/null
 mkdir -p ../../build/obj_$tag
