@@ -73,6 +73,7 @@ typedef struct mk_stats_t {
   uint64_t part_reused;  /* chunks that inherited the bucket regions of the chunk before them (no histogram, no scan) */
   uint64_t fused_chunks; /* chunks whose count kernel put the survivors into the running table itself (ABI 4)        */
   uint64_t fuse_spilled; /* ... survivors of those it set aside instead (table filling up), imported afterwards        */
+  uint64_t parse_retries; /* chunks parsed a second time by the general parser (a blank inside a sequence line)           */
 } mk_stats_t;
 
 /* ---- lifetime ------------------------------------------------------------------------- */

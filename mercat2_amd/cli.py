@@ -154,7 +154,8 @@ def main(argv=None) -> int:
             t0 = timeit.default_timer()
             raw = read_fasta_bytes(f)
             t["read_s"] = timeit.default_timer() - t0
-            path, fut, holder = removeN_background(f, raw, out / "clean", args.toupper, gz_writers, timings=t)
+            path, fut, holder = removeN_background(f, raw, out / "clean", args.toupper, gz_writers, timings=t,
+                                                   limit=args.s * 1024 * 1024)
             return base, [path, raw, fut, holder, t]
         with ThreadPoolExecutor(max(1, min(int(args.n), 8, len(samples["nucleotide"])))) as pool:
             for base, job in pool.map(load, samples["nucleotide"].items()):
@@ -207,12 +208,43 @@ def main(argv=None) -> int:
                     else:
                         # the sample may be chunked (the reference cuts the CLEANED file, and its size on disk decides,
                         # bin/mercat2.py:101, 243), or holds text whose rewrite the GPU does not reproduce: count the text
-                        # the host rewrite produced
-                        gz_size, _stats = fut.result()
+                        # the host rewrite produced (native, memory speed) -- without waiting for the level-9 gzip of the
+                        # clean file: a DEFLATE stream only grows, so "chunked" is known the moment its bytes pass -s MiB.
+                        holder["ready"].wait()
+                        if "text" not in holder:
+                            fut.result()  # (the rewrite failed: its exception surfaces here, as it would in MerCat2)
                         text = holder.pop("text")
-                        chunked = args.s > 0 and gz_size >= limit
-                        run_text(base, text, tsv, args.k, args.c, args.s, chunked, device=home, devices=devices if chunked else None,
-                                 streams=args.streams, canonical=args.canonical, report=lines.append, keep=tables, timings=t)
+                        decision = holder["decision"]
+                        kw = dict(device=home, streams=args.streams, canonical=args.canonical, timings=t)
+                        # the .gz cannot be larger than the text plus the stored-block overhead zlib falls back to
+                        certain_whole = args.s <= 0 or len(text) + len(text) // 1000 + 4096 < limit
+                        chunked = False if certain_whole else decision.wait(0)
+                        if chunked is not None:
+                            run_text(base, text, tsv, args.k, args.c, args.s, chunked, devices=devices if chunked else None,
+                                     report=lines.append, keep=tables, **kw)
+                        else:
+                            # not known yet: count BOTH tables now (milliseconds each), publish the one the size selects
+                            t_wait = timeit.default_timer()
+                            cand = {}
+                            for name, ch in (("whole", False), ("chunked", True)):
+                                lc, kc = [], {}
+                                run_text(base, text, str(tsv) + "." + name, args.k, args.c, args.s, ch, devices=devices if ch else None,
+                                         report=lc.append, keep=kc, **kw)
+                                cand[ch] = (str(tsv) + "." + name, lc, kc)
+                            chunked = decision.wait()
+                            if chunked is None:
+                                fut.result()  # (the gzip writer failed)
+                            t["decide_s"] = timeit.default_timer() - t_wait
+                            path_, lc, kc = cand[bool(chunked)]
+                            if os.path.exists(path_):
+                                os.replace(path_, tsv)
+                            lines.extend(lc)
+                            tables.update(kc)
+                            other_path, _, other_keep = cand[not chunked]
+                            if os.path.exists(other_path):
+                                os.unlink(other_path)
+                            for ctx_ in other_keep.values():
+                                ctx_.close()
                         del text
                 t.update(t_load)
             else:

@@ -224,6 +224,7 @@ extern "C" void mk_destroy(mk_ctx* c) {
   for (auto* b : all) buf_free(*b);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->ingest_ring) (void)hipHostFree(c->ingest_ring);
+  if (c->tsv_pin) { (void)hipHostUnregister(c->tsv_pin); free(c->tsv_pin); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -490,7 +491,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   const bool fused = !two && c->fused_last;
   if ((rc = pull_info(c)) != MK_OK) return rc;  // the one read-back
   MkChunkInfo* h = c->h_info;
-  if (h->parse_fallback) return MK_RETRY_GENERAL;
+  if (h->parse_fallback) { c->st.parse_retries += 1; return MK_RETRY_GENERAL; }
   if (h->non_ascii) {
     c->err = "input holds " + std::to_string(h->non_ascii) +
              " sequence byte(s) >= 0x80 (non-ASCII sequence text is not supported; the chunk was not counted)";
@@ -591,6 +592,7 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
 // bytes in front; only the (rare) general-parser fallback needs an aligned copy.
 static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_count) {
   int rc;
+  bool known_blank = false;
   if (c->clean_mode) {  // (one read-back more than the speculative lane: the chunk must be known to be reproducible BEFORE it is merged)
     if (!c->use_fast_parse) { c->err = "clean mode needs the fast parser (MK_NO_FAST_PARSE is set)"; return MK_ERR_UNSUPPORTED; }
     if (d_raw != (const uint8_t*)c->raw.p) { c->err = "clean mode rewrites the text in place: feed it (mk_chunk_feed), do not pass caller memory"; return MK_ERR_STATE; }
@@ -602,6 +604,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
        (c->mode == MK_MODE_HASH128 && c->use_superkmer2))) {
     rc = process_chunk_fast(c, d_raw, n, min_count);
     if (rc != MK_RETRY_GENERAL) return rc;
+    known_blank = true;  // (the fast parser has just said so: straight to the general one)
   }
   if ((rc = settle(c)) != MK_OK) return rc;
   const size_t begin = (size_t)((uintptr_t)d_raw & 15);
@@ -617,7 +620,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
     if ((rc = mk_buf_reserve(c, c->codes, (code_words + 8) * 8)) != MK_OK) return rc;
   }
   for (int attempt = 0; attempt < 2; ++attempt) {
-    const bool fast = c->use_fast_parse && attempt == 0;
+    const bool fast = c->use_fast_parse && attempt == 0 && !known_blank;
     const bool fused = fast && packed && c->alphabet == MK_ALPHABET_NT2;  // the nt pack rides on the parser's LDS image
     if (!fast && begin) {  // aligned copy for the general transducer
       if ((rc = mk_buf_reserve(c, c->raw, n + 64)) != MK_OK) return rc;
@@ -650,6 +653,7 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
       break;
     }
     if (!fast || !c->h_info->parse_fallback) break;
+    c->st.parse_retries += 1;
     // a blank inside a sequence line: the general transducer handles strip() exactly
     MK_HIP(hipMemsetAsync(c->info.p, 0, sizeof(MkChunkInfo), c->stream));
   }
@@ -1080,8 +1084,115 @@ extern "C" int mk_export(mk_ctx* c, uint8_t* kmers, uint64_t* counts, size_t row
   return MK_OK;
 }
 
+// mk_tsv.hip: sorted device rows -> TSV text in c->seq
+int mk_launch_tsv_format(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_cnts, size_t rows, int words, uint64_t* d_len,
+                         uint64_t* d_off, size_t* text_bytes);
+
+// The table written from the device: compaction and sort as for any export, the rows formatted by a kernel (mk_tsv.hip),
+// the text copied out through two pinned blocks while the one before is written to the file.  For tables whose rows are
+// all packed keys (no rows kept as text: those are merged in on the host, write_view_tsv).
+static int write_tsv_from_device(mk_ctx* c, const char* path, const char* basename, size_t* rows_out) {
+  using Clk = std::chrono::steady_clock;
+  auto since = [](Clk::time_point t) { return std::chrono::duration<double>(Clk::now() - t).count(); };
+  MK_HIP(hipSetDevice(c->device));
+  int rc;
+  if ((rc = settle(c)) != MK_OK) return rc;
+  const auto t0 = Clk::now();
+  c->ex_st = mk_export_stats_t{};
+  const int words = c->mode == MK_MODE_HASH128 ? 2 : 1;
+  size_t cap = 0;
+  if (c->mode == MK_MODE_DENSE) cap = c->run_slots;
+  else if (c->mode == MK_MODE_HASH64) cap = c->run_rows + 1;
+  else cap = c->run128_rows;
+  if (rows_out) *rows_out = 0;
+  if (!cap) return MK_OK;
+  MkDevBuf& kb = c->mode == MK_MODE_HASH128 ? c->ex128_out : c->ex_keys2;
+  if ((rc = mk_buf_reserve(c, kb, (cap * (size_t)words + cap) * 8 + 64)) != MK_OK) return rc;  // keys, then counts
+  u64* d_keys = (u64*)kb.p;
+  u64* d_cnts = d_keys + cap * (size_t)words;
+  ExportView v;
+  size_t rows = 0;
+  if ((rc = gather_packed(c, v, d_keys, d_cnts, cap, &rows, /*to_host=*/false)) != MK_OK) return rc;
+  MK_HIP(hipStreamSynchronize(c->stream));
+  c->ex_st.s_sort = since(t0);
+  c->ex_st.rows = rows;
+  if (rows_out) *rows_out = rows;
+  if (!rows) return MK_OK;  // bin/mercat2.py:135-137: no file when nothing survives
+  const auto t1 = Clk::now();
+  // offsets and lengths: two scratch arrays of rows + 1 words (the compaction's buffers are free again)
+  if ((rc = mk_buf_reserve(c, c->ex_keys, (rows + 1) * 8 + 64)) != MK_OK) return rc;
+  if ((rc = mk_buf_reserve(c, c->ex_cnts, (rows + 1) * 8 + 64)) != MK_OK) return rc;
+  size_t text = 0;
+  if ((rc = mk_launch_tsv_format(c, (const uint64_t*)d_keys, (const uint64_t*)d_cnts, rows, words, (uint64_t*)c->ex_keys.p,
+                                 (uint64_t*)c->ex_cnts.p, &text)) != MK_OK) return rc;
+  // two registered blocks, kept with the context
+  const size_t piece = (size_t)8 << 20;
+  if (c->tsv_pin_bytes < 2 * piece) {
+    void* p = aligned_alloc(4096, 2 * piece);
+    if (!p) { c->err = "mk_write_tsv: out of host memory"; return MK_ERR_NOMEM; }
+    memset(p, 0, 2 * piece);  // (touched before it is pinned)
+    const hipError_t he0 = hipHostRegister(p, 2 * piece, hipHostRegisterDefault);
+    if (he0 != hipSuccess) { free(p); c->err = std::string("hipHostRegister: ") + hipGetErrorString(he0); return MK_ERR_HIP; }
+    c->tsv_pin = p;
+    c->tsv_pin_bytes = 2 * piece;
+  }
+  char* pin[2] = {(char*)c->tsv_pin, (char*)c->tsv_pin + piece};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  for (auto& e : ev) MK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  FILE* f = fopen(path, "wb");
+  if (!f) {
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    c->err = std::string("mk_write_tsv: cannot open ") + path;
+    return MK_ERR_IO;
+  }
+  setvbuf(f, nullptr, _IONBF, 0);  // (whole blocks: no second copy through stdio's buffer)
+  const std::string head = std::string("k-mer\t") + basename + "_Count\n";
+  double s_write = 0, s_wait = 0;
+  auto timed_write = [&](const void* p, size_t n) {
+    const auto tw = Clk::now();
+    const size_t put = fwrite(p, 1, n, f);
+    s_write += since(tw);
+    return put == n;
+  };
+  bool ok = timed_write(head.data(), head.size());
+  const size_t npieces = (text + piece - 1) / piece;
+  hipError_t he = hipSuccess;
+  for (size_t i = 0; i <= npieces && ok && he == hipSuccess; ++i) {
+    if (i < npieces) {  // copy piece i out while piece i - 1 is written
+      const size_t a = i * piece, n = std::min(piece, text - a);
+      he = hipMemcpyAsync(pin[i & 1], (const char*)c->seq.p + a, n, hipMemcpyDeviceToHost, c->stream);
+      if (he == hipSuccess) he = hipEventRecord(ev[i & 1], c->stream);
+    }
+    if (i > 0 && he == hipSuccess) {
+      const size_t a = (i - 1) * piece, n = std::min(piece, text - a);
+      const auto tw = Clk::now();
+      he = hipEventSynchronize(ev[(i - 1) & 1]);
+      s_wait += since(tw);
+      if (he == hipSuccess) ok = timed_write(pin[(i - 1) & 1], n);
+    }
+  }
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  const auto tc = Clk::now();
+  const bool bad_close = fclose(f) != 0;
+  s_write += since(tc);
+  const double all = since(t1);
+  c->ex_st.bytes = head.size() + text;
+  c->ex_st.s_write = s_write;
+  c->ex_st.s_d2h = s_wait;
+  c->ex_st.s_format = all - s_write - s_wait;  // (lengths, scan, fill kernel and what the loop itself costs)
+  c->ex_st.s_total = since(t0);
+  if (he != hipSuccess) { c->err = std::string("mk_write_tsv: copy of the text: ") + hipGetErrorString(he); return MK_ERR_HIP; }
+  if (!ok || bad_close) { c->err = std::string("mk_write_tsv: write failed: ") + path; return MK_ERR_IO; }
+  return MK_OK;
+}
+
 extern "C" int mk_write_tsv(mk_ctx* c, const char* path, const char* basename, size_t* rows_out) {
   if (!c || !path || !basename) return MK_ERR_ARG;
+  { int rc_ = settle(c); if (rc_) return rc_; }
+  static const bool host_only = getenv("MK_TSV_HOST") != nullptr;  // (A/B and tests: the host formatter for every table)
+  if (!host_only && c->mode != MK_MODE_BYREF && c->run_ref_rows == 0 && c->bits != 0)
+    return write_tsv_from_device(c, path, basename, rows_out);
   ExportView v;
   int rc = build_view(c, v);
   if (rc) return rc;

@@ -204,6 +204,10 @@ struct mk_ctx {
   // pinned block ring of mk_count_file (mk_ingest.hip), kept between files
   void* ingest_ring = nullptr;
   size_t ingest_ring_bytes = 0;
+  // two blocks the TSV text is copied out through (mk_write_tsv): ordinary (cached) memory, registered with the driver --
+  // the CPU READS these, and it read hipHostMalloc'ed memory at 3.5 GB/s
+  void* tsv_pin = nullptr;
+  size_t tsv_pin_bytes = 0;
 
   // stats
   mk_stats_t st{};

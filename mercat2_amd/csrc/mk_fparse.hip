@@ -150,12 +150,14 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
     const unsigned e0 = wave_step(nl, gt, st, low, prev_nl, s0, out, sep, bl, last_nl);
     c0 += __popc(out);
     seps += __popc(sep);  // '>' at a line start: the same whatever the entry state
-    flag_low |= bl;
+    // (a blank inside a sequence line is looked for by the EMIT pass, which knows the wave's true entry state: under
+    // the wrong one of the two assumed here every blank of a header line that the wave starts inside looked like one,
+    // and read files whose header lines hold blanks -- most do -- fell back to the general parser, chunk after chunk)
+    (void)bl;
     if (s1 != s0) {
       unsigned out1, sep1, bl1, ln1;
       const unsigned e1 = wave_step(nl, gt, st, low, prev_nl, s1, out1, sep1, bl1, ln1);
       c1 += __popc(out1);
-      flag_low |= bl1;
       s1 = e1;
     } else {
       c1 += __popc(out);
@@ -170,11 +172,10 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
     c1 += __shfl_down(c1, d);
     seps += __shfl_down(seps, d);
   }
-  const bool any_low = __ballot(flag_low != 0) != 0;
+  (void)flag_low;
   if (lane == 0) {
     entries[wave].a = any_nl | (s0 << 1) | (seps << 2);
     entries[wave].b = c0 | (c1 << 16);
-    if (any_low) atomicOr(&info->parse_fallback, 1ull);
   }
 }
 
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   unsigned state = sc.st;
   unsigned filled = 0;   // bytes emitted so far by this wave
   int nbad = 0;          // kept characters outside the alphabet (separators subtracted: they are marked bad, not counted)
+  unsigned flag_low = 0;
   unsigned nhi = 0;      // KEPT bytes >= 0x80: sequence characters the reference would decode as multi-byte text
                          // (bytes of header lines never enter a k-mer: lib/mercat2_kmers.py:52-53)
 #pragma unroll 1
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
     unsigned out, sep, bl, last_nl;
     state = wave_step(nl, gt, st, low, prev_nl, state, out, sep, bl, last_nl);
     prev_nl = last_nl;
+    flag_low |= bl;  // a blank (or control byte) outside header lines: this parser's assumption does not hold
     const unsigned cnt = __popc(out);
     nbad -= (int)__popc(sep);
     nhi += __popc(hi & out & ~sep);
@@ -431,6 +434,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
   // (without the fused pack nobody reads the sum: the pack kernel counts the bad symbols)
   for (int d = 32; d > 0; d >>= 1) nbad += __shfl_down(nbad, d);
   if (codes && lane == 0 && nbad > 0) atomicAdd(&info->bad_symbols, (u64)nbad);
+  if (__ballot(flag_low != 0) && lane == 0) atomicOr(&info->parse_fallback, 1ull);  // the host re-parses the chunk generally
   if (__ballot(nhi != 0)) {  // (never, for ASCII input)
     for (int d = 32; d > 0; d >>= 1) nhi += __shfl_down(nhi, d);
     if (lane == 0) atomicAdd(&info->non_ascii, (u64)nhi);

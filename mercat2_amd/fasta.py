@@ -27,31 +27,101 @@ def clean_text(raw, toupper: bool = False) -> Tuple[bytes, Dict[str, float]]:
     return cleaned, {"GC Content": 100.0 * st["gc_count"] / st["total_length"]}
 
 
-def _write_clean_gz(out_fasta: Path, cleaned, timings: Optional[dict] = None) -> int:
+class GzDecision:
+    """Whether ``<base>_clean.fna.gz`` reaches ``limit`` bytes -- what decides about chunking (bin/mercat2.py:101) -- as soon as
+    that is known: a DEFLATE stream only grows, so the answer is "yes" the moment the bytes written pass the limit, and
+    "no" only when the file is complete.  ``wait()`` blocks until then; ``size`` is the bytes written so far."""
+
+    def __init__(self, limit: int):
+        import threading
+        self.limit = int(limit)
+        self.size = 0
+        self.chunked: Optional[bool] = None
+        self._event = threading.Event()
+
+    def _grew(self, size: int, complete: bool) -> None:
+        self.size = size
+        if self.chunked is None:
+            if self.limit > 0 and size >= self.limit:
+                self.chunked = True
+                self._event.set()
+            elif complete:
+                self.chunked = False
+                self._event.set()
+
+    def _failed(self) -> None:
+        self._event.set()  # (the writer's exception surfaces through its future)
+
+    def wait(self, timeout: Optional[float] = None) -> Optional[bool]:
+        self._event.wait(timeout)
+        return self.chunked
+
+
+class _CountingFile:
+    """The raw file under GzipFile: counts what reaches it."""
+
+    def __init__(self, path, decision: Optional[GzDecision]):
+        self._f = open(path, "wb")
+        self._n = 0
+        self._d = decision
+
+    def write(self, data):
+        n = self._f.write(data)
+        self._n += len(data)
+        if self._d is not None:
+            self._d._grew(self._n, False)
+        return n
+
+    def flush(self):
+        self._f.flush()
+
+    def close(self):
+        self._f.close()
+
+
+def _write_clean_gz(out_fasta: Path, cleaned, timings: Optional[dict] = None, decision: Optional[GzDecision] = None) -> int:
     """<base>_clean.fna.gz exactly as the reference's text-mode gzip writer leaves it (level 9, one flush on close):
-    its SIZE decides whether the sample is chunked (bin/mercat2.py:101).  Returns that size."""
+    its SIZE decides whether the sample is chunked (bin/mercat2.py:101).  Returns that size.  The text is handed to
+    zlib in 1 MiB slices (the stream does not depend on how its input is sliced: tests/test_clean.py), so that
+    ``decision`` learns that the limit has been passed while the rest is still being compressed."""
     import timeit
     t0 = timeit.default_timer()
-    with gzip.open(out_fasta, "wb") as writer:
-        writer.write(cleaned)
-        writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
+    raw = _CountingFile(out_fasta, decision)
+    try:
+        # (GzipFile names the member after `filename` and takes the bytes to `fileobj`: the same header gzip.open writes)
+        with gzip.GzipFile(filename=os.fspath(out_fasta), mode="wb", fileobj=raw) as writer:
+            mv = memoryview(cleaned)
+            for a in range(0, len(mv), 1 << 20):
+                writer.write(mv[a:a + (1 << 20)])
+            writer.flush()  # the reference's text-mode writer flushes once when it is closed: one sync-flush marker in the stream
+        raw.close()
+    except BaseException:
+        raw.close()
+        if decision is not None:
+            decision._failed()
+        raise
+    size = os.stat(out_fasta).st_size
+    if decision is not None:
+        decision._grew(size, True)
     if timings is not None:
         timings["gzip_s"] = timeit.default_timer() - t0
-    return os.stat(out_fasta).st_size
+    return size
 
 
-def removeN_background(fasta: Path, raw, outpath: Path, toupper: bool, writers, timings: Optional[dict] = None):
+def removeN_background(fasta: Path, raw, outpath: Path, toupper: bool, writers, timings: Optional[dict] = None, limit: int = 0):
     """The whole of removeN -- rewrite and ``<base>_clean.fna.gz`` -- on the executor ``writers``, from the file's bytes
     ``raw`` already in memory: for samples whose table the GPU takes from the raw text (harness.run_raw_clean), so that
     nothing of removeN stands in front of the first kernel.  Returns ``(path, future, holder)``; ``future.result()`` is
     ``(size of the finished .gz, stats)``; the cleaned bytes are left in ``holder["text"]`` unless the caller has
-    called ``holder["drop"]()`` (it did not need them: no reason to keep a second copy of the sample in memory)."""
+    called ``holder["drop"]()`` (it did not need them: no reason to keep a second copy of the sample in memory).
+    ``holder["ready"]`` is set when the rewrite is done (the text is there, or the job has failed); ``holder["decision"]``
+    is the GzDecision of the file against ``limit`` bytes (0: no limit: "not chunked" once the file is complete)."""
     import threading
     os.makedirs(outpath, exist_ok=True)
     basename = Path(fasta).stem.split(".")[0]
     out_fasta = Path(outpath, f"{basename}_clean.fna.gz")
     lock = threading.Lock()
-    holder = {"dropped": False}
+    holder = {"dropped": False, "ready": threading.Event(), "decision": GzDecision(limit)}
 
     def drop():
         with lock:
@@ -62,13 +132,19 @@ def removeN_background(fasta: Path, raw, outpath: Path, toupper: bool, writers, 
     def job():
         import timeit
         t0 = timeit.default_timer()
-        cleaned, stats = clean_text(raw, toupper)
+        try:
+            cleaned, stats = clean_text(raw, toupper)
+        except BaseException:
+            holder["ready"].set()
+            holder["decision"]._failed()
+            raise
         if timings is not None:
             timings["clean_s"] = timeit.default_timer() - t0
         with lock:
             if not holder["dropped"]:
                 holder["text"] = cleaned
-        return _write_clean_gz(out_fasta, cleaned, timings), stats
+        holder["ready"].set()
+        return _write_clean_gz(out_fasta, cleaned, timings, holder["decision"]), stats
     return out_fasta.absolute(), writers.submit(job), holder
 
 

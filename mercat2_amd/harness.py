@@ -36,13 +36,16 @@ def countKmers(file, kmer: int, min_count: int, device: int = 0):
     return find_kmers(Path(file), kmer, min_count, device=device)
 
 
-# Small samples are dominated by fixed costs: creating an engine context (stream, pinned and device
-# allocations) takes ~3 ms, counting a 100 KB file ~1.5 ms.  Contexts that last served a small sample are
-# kept (reset, with their small buffers) and handed to the next sample with the same shape.
+# Every sample pays fixed costs when it starts from nothing: creating an engine context (stream, pinned and device
+# allocations) takes ~3 ms, the pinned block ring of mk_count_file ~5 ms, and a large sample's working buffers (~3 GB
+# per context for 100 MiB chunks) are allocated chunk by chunk and freed -- each hipFree a device-wide wait -- when the
+# context is closed: 16 of the 132 ms of a 1.6 GB sample (bench.py file_to_tsv, round 4).  Contexts are therefore kept
+# (reset, WITH their buffers and their ring) and handed to the next sample of the same shape: up to _POOL_MAX_PER_KEY per
+# (k, alphabet, device, canonical), _POOL_MAX in all -- a node has 288 GB per GPU; release_pool() gives the memory back.
 _POOL: dict = {}
 _POOL_LOCK = threading.Lock()
 _POOL_MAX_PER_KEY = 8
-_POOL_SMALL = 32 << 20  # bytes of text a pooled context may have seen in its last sample
+_POOL_MAX = 24
 
 
 def _take_context(k: int, alphabet: int, device: int, canonical: bool) -> native.Counter:
@@ -54,13 +57,13 @@ def _take_context(k: int, alphabet: int, device: int, canonical: bool) -> native
 
 
 def _give_back(ctx: native.Counter, key, text_bytes: int) -> None:
-    if text_bytes <= _POOL_SMALL:
+    if text_bytes < (1 << 62):  # (1 << 62: the context saw an error, or its sample was not finished)
         try:
             ctx.reset()
             ctx.reset_stats()
             with _POOL_LOCK:
                 idle = _POOL.setdefault(key, [])
-                if len(idle) < _POOL_MAX_PER_KEY:
+                if len(idle) < _POOL_MAX_PER_KEY and sum(len(v) for v in _POOL.values()) < _POOL_MAX:
                     idle.append(ctx)
                     return
         except native.MercatHipError:
@@ -68,13 +71,18 @@ def _give_back(ctx: native.Counter, key, text_bytes: int) -> None:
     ctx.close()
 
 
-@atexit.register
-def _drain_pool() -> None:
+def release_pool() -> None:
+    """Close the idle contexts kept for the next sample (their device and pinned memory is freed)."""
     with _POOL_LOCK:
         for idle in _POOL.values():
             for ctx in idle:
                 ctx.close()
         _POOL.clear()
+
+
+@atexit.register
+def _drain_pool() -> None:
+    release_pool()
 
 
 def _device_list(device: int, devices: Optional[Sequence[int]]) -> List[int]:

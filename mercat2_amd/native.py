@@ -60,7 +60,7 @@ class Stats(C.Structure):
                [(n, C.c_double) for n in ("ms_parse", "ms_pack", "ms_count", "ms_exotic", "ms_filter", "ms_export")] + \
                [(n, C.c_uint64) for n in ("n_parse", "n_pack", "n_count", "n_exotic", "n_filter", "n_export")] + \
                [("ms_part", C.c_double), ("n_part", C.c_uint64), ("records", C.c_uint64), ("distinct", C.c_uint64),
-                ("part_retries", C.c_uint64), ("part_reused", C.c_uint64), ("fused_chunks", C.c_uint64), ("fuse_spilled", C.c_uint64)]
+                ("part_retries", C.c_uint64), ("part_reused", C.c_uint64), ("fused_chunks", C.c_uint64), ("fuse_spilled", C.c_uint64), ("parse_retries", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -164,3 +164,40 @@ def test_native_rewrite_equals_the_oracle_restatement_on_random_text():
             assert st["unsupported_record"] == -1
             assert got == want.encode(), (case, up, text)
             assert (st["gc_count"], st["total_length"]) == (gc, total), (case, up, text)
+
+
+def test_clean_gz_writer_streams_and_decides_early(tmp_path):
+    """<base>_clean.fna.gz is written in slices -- same bytes as one gzip.open(...).write(...) but for the time stamp --
+    and the chunking decision (its size against -s MiB, bin/mercat2.py:101) is out as soon as the stream has passed
+    the limit, not when the file is complete; below the limit it is out when the file is."""
+    import gzip
+    import random
+    from mercat2_amd import fasta
+    random.seed(5)
+    body = bytes(random.choice(b"ACGT") for _ in range(2_500_000))
+    text = b">x some text\n" + b"\n".join(body[i:i + 80] for i in range(0, len(body), 80)) + b"\n"
+    ref = tmp_path / "ref" / "x_clean.fna.gz"
+    ref.parent.mkdir()
+    with gzip.open(ref, "wb") as w:  # what the reference's writer does (text mode: one flush at close)
+        w.write(text)
+        w.flush()
+    seen = []
+
+    class Spy(fasta.GzDecision):
+        def _grew(self, size, complete):
+            was = self.chunked
+            super()._grew(size, complete)
+            if was is None and self.chunked is not None:
+                seen.append((size, complete))
+    out = tmp_path / "out" / "x_clean.fna.gz"
+    out.parent.mkdir()
+    d = Spy(200_000)
+    size = fasta._write_clean_gz(out, text, decision=d)
+    a, b = ref.read_bytes(), out.read_bytes()
+    assert size == len(b) == len(a) and a[:4] == b[:4] and a[8:] == b[8:]  # (bytes 4..7: the time stamp)
+    assert gzip.decompress(b) == text
+    assert d.wait(0) is True and seen and seen[0][1] is False and 200_000 <= seen[0][0] < size // 2
+    d2 = fasta.GzDecision(size + 1)
+    assert fasta._write_clean_gz(out, text, decision=d2) == size and d2.wait(0) is False
+    d3 = fasta.GzDecision(0)  # -s 0: never chunked
+    assert fasta._write_clean_gz(out, text, decision=d3) == size and d3.wait(0) is False

@@ -377,6 +377,56 @@ def test_cli_nucleotide_default_runs_removeN_first(tmp_path, capsys):
         cli.main(["-i", str(fq), "-k", "5", "-o", str(tmp_path / "y")])
 
 
+def test_cli_counts_both_tables_until_the_clean_gz_decides(tmp_path, capsys):
+    """A nucleotide FASTA whose CLEANED text reaches -s MiB: whether MerCat2 chunks it depends on the size of the level-9
+    clean/<base>_clean.fna.gz (bin/mercat2.py:101, 243).  The CLI counts both candidates from the rewritten text and
+    publishes the one the growing .gz selects: (a) a text whose .gz passes the limit -> the chunked table (the Chunker's
+    cuts of the CLEANED text, every chunk filtered on its own), (b) one whose .gz stays below -> the unchunked table."""
+    import gzip
+    import io
+    from mercat2_amd import cli
+    from oracle import clean_ref
+    rng = np.random.default_rng(9)
+
+    def sample(name, bases, genome):
+        recs, i = [], 0
+        g = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=genome).tobytes()
+        total = 0
+        while total < bases:
+            a = int(rng.integers(0, genome - 400))
+            seq = bytearray(g[a:a + 400])
+            if i % 7 == 0:
+                seq[100:100 + int(rng.integers(1, 30))] = b"N" * len(seq[100:100 + int(rng.integers(1, 30))])
+            recs.append(b">s%d d\n" % i + b"\n".join(bytes(seq[j:j + 70]) for j in range(0, len(seq), 70)) + b"\n")
+            total += 400
+            i += 1
+        p = tmp_path / (name + ".fna")
+        p.write_bytes(b"".join(recs))
+        return p
+    # (a): a large genome compresses to ~0.29 of the text -> 5 MB of text gives ~1.4 MiB of .gz; (b): reads of a tiny
+    # genome compress far below the limit although the text is above it
+    for name, bases, genome, want_chunked in (("big", 5_000_000, 4_000_000, True), ("rep", 2_500_000, 3_000, False)):
+        src = sample(name, bases, genome)
+        out = tmp_path / ("res_" + name)
+        assert cli.main(["-i", str(src), "-k", "21", "-c", "2", "-s", "1", "-o", str(out), "-debug"]) == 0
+        printed = capsys.readouterr().out
+        gz = out / "clean" / (name + "_clean.fna.gz")
+        cleaned = gzip.open(gz, "rb").read()
+        assert cleaned == clean_ref.clean_text(src.read_bytes().decode(), False)[0].encode()
+        assert len(cleaned) >= 1 << 20, "the case must be one the text's size alone does not decide"
+        assert (gz.stat().st_size >= (1 << 20)) == want_chunked
+        if want_chunked:
+            groups = cpu_ref.split_lines(io.TextIOWrapper(io.BytesIO(cleaned), encoding="utf-8", newline=None), 1 << 20)
+            assert len(groups) > 2
+            table = cpu_ref.merge_counts(cpu_ref.count_lines(g, 21, 2) for g in groups)
+        else:
+            table = cpu_ref.count_text(cleaned, 21, 2)
+        tsv = out / "tsv_nucleotide" / (name + "_counts.tsv")
+        assert tsv.read_text() == cpu_ref.tsv_text(name, table)
+        assert not list((out / "tsv_nucleotide").glob("*.whole")) and not list((out / "tsv_nucleotide").glob("*.chunked"))
+        assert "decide_s=" in printed and printed.count("Significant k-mers:") == 1
+
+
 def _fold_filter(table, c):
     return {key: n for key, n in cpu_ref.canonical_fold(table).items() if n >= c}
 
@@ -547,6 +597,34 @@ def test_fuzz_against_oracle():
             got = ctx.to_dict()
         want = cpu_ref.merge_counts(c_oracle.count_dict(data[a:b], k, c) for a, b in zip(offs[:-1], offs[1:]))
         assert got == want, (trial, kind, k, c, len(data), len(offs))
+
+
+def test_blanks_in_header_lines_keep_the_fast_parser():
+    """Read files whose header lines hold blanks (">SRR1.7 7 length=150": most real ones) stay on the fast parser --
+    up to round 3 its first pass, which tries both entry states of a wave, took the blanks of a header line it started
+    inside for blanks in sequence text and sent the whole chunk to the general parser (three times the work of the rest
+    of the pipeline).  A blank inside a SEQUENCE line still takes the general parser, and both are exact."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=20000).tobytes()
+    recs = []
+    for i in range(6000):
+        a = int(rng.integers(0, len(genome) - 150))
+        recs.append(b">SRR000001.%d %d length=150 some\ttext\n" % (i, i) + genome[a:a + 150] + b"\n")
+    data = b"".join(recs)
+    for k, c in ((31, 2), (21, 1), (63, 2), (5, 10)):
+        with native.Counter(k, native.ALPHABET_NT2) as ctx:
+            ctx.count_chunk(data, c)
+            assert ctx.to_dict() == c_oracle.count_dict(data, k, c), (k, c)
+            assert ctx.stats()["parse_retries"] == 0, (k, c)
+    spoiled = data.replace(genome[300:320], genome[300:310] + b" " + genome[310:320], 1)
+    assert spoiled != data
+    with native.Counter(31, native.ALPHABET_NT2) as ctx:
+        ctx.count_chunk(spoiled, 2)
+        ctx.count_chunk(spoiled, 2)  # (the second chunk of a sample would be a fused launch: it must stand back too)
+        want = c_oracle.count_dict(spoiled, 31, 2)
+        assert ctx.to_dict() == {key: 2 * n for key, n in want.items()}
+        assert ctx.stats()["parse_retries"] == 2
 
 
 def test_long_lines_and_long_headers():
