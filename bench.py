@@ -578,7 +578,7 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in
         # separate rocprofv3 runs of this command, gfx950 correction applied: tools/trim_profiles.py)
         traffic, traffic_src = None, None
-        for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
             pmc_file = ROOT / "profiles" / name
             if pmc_file.exists() and args.reads == READS and k == K and not canonical:
                 pmc = json.loads(pmc_file.read_text())
