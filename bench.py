@@ -207,6 +207,9 @@ def main():
                          "instead of one process per GPU over RCCL")
     ap.add_argument("--merge-rccl", action="store_true",
                     help="--single-process: the segments of mk_merge_devices travel over RCCL (MK_MERGE_RCCL) instead of peer copies")
+    ap.add_argument("--no-share", action="store_true",
+                    help="every context sums its chunks' survivors into a table of its own (as up to round 3) instead of the "
+                         "contexts of a GPU sharing the first one's (mk_share_table)")
     ap.add_argument("--no-single-leg", action="store_true",
                     help="N > 1, one process per GPU: do not run the one-process product path (mk_merge_devices) in a fresh child afterwards")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the cpu_baseline leg (default: the physical cores available)")
@@ -220,7 +223,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=int(os.environ.get("MK_BENCH_CONTEXTS", "0")),
                     help="engine contexts (HIP streams) per GPU; chunks are dealt round-robin and counted "
                          "concurrently, the tables are merged on the device at the end of the step")
-    args = ap.parse_args()
+    args = ap.parse_args(sys.argv[1:] + os.environ.get("MK_BENCH_EXTRA", "").split())  # (MK_BENCH_EXTRA: more flags, for A/B scripts)
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -288,6 +291,12 @@ def main():
             self.by_dev = [[native.Counter(k, native.ALPHABET_NT2, device=d, canonical=canonical) for _ in range(nctx)] for d in devices]
             self.leaders = [c[0] for c in self.by_dev]
             self.all = [c for cs in self.by_dev for c in cs]
+            # the contexts of one GPU upsert their chunks' survivors into ONE running table, the leader's (mk_share_table)
+            self.shared = not args.no_share and self.leaders[0].stats()["mode_name"] == "hash64"
+            if self.shared:
+                for cs in self.by_dev:
+                    for c in cs[1:]:
+                        c.share_table(cs[0])
             self.pool = ThreadPoolExecutor(len(self.all)) if len(self.all) > 1 else None
             self.words = self.leaders[0].words_per_key()
             self.key_bits = 2 * k
@@ -301,8 +310,10 @@ def main():
         def close(self):
             if self.pool:
                 self.pool.shutdown()
+                self.pool = None
             for c in self.all:
                 c.close()
+            self.all, self.leaders, self.by_dev = [], [], []
 
         def make_step(self, parts_by_dev):
             jobs = []  # (context, its chunks)
@@ -313,9 +324,16 @@ def main():
 
             def count_share(job):
                 c, mine = job
-                c.reset()
+                if not self.shared:
+                    c.reset()
                 for ptr, n in mine:  # every chunk is filtered on its own (the per-chunk -c rule)
                     c.count_device(ptr, n, MIN_COUNT)
+
+            def reset_all():
+                # (a shared table is cleared before any context counts into it again: the owner's reset and the sharers'
+                # chunks are not ordered otherwise)
+                for c in self.all:
+                    c.reset()
 
             def finish_device(di):
                 lead = self.leaders[di]
@@ -331,6 +349,8 @@ def main():
                 # (every phase ends with a host wait of its own -- the last chunk's read-back, the merge's import, the
                 # export's row count -- so plain clocks split the step without adding a synchronisation to it)
                 t0 = time.perf_counter()
+                if self.shared:
+                    reset_all()
                 if self.pool is None:
                     count_share(jobs[0])
                 else:
@@ -522,6 +542,10 @@ def main():
     default_run = (args.reads, args.genome, k, args.sub_ppm, canonical) == (READS, GENOME, K, 0, False)
     if ngpu == 1 and rank == 0 and default_run and not args.no_configs:
         configs = {}
+        # (the main engine's contexts go first: HIP spreads a process's streams over a few hardware queues, and with the
+        # main engine's two streams still alive the two streams of a leg's engine landed on ONE queue -- their kernels ran
+        # one after the other, config 3 measured 14.6-15.5 ms as a leg against 12.7-13.0 ms as a run of its own)
+        eng.close()
 
         def short_run(name, kk, canon, reads, genome, gseed, rseed, steps, parts_in=None, warm=2):
             e2 = Engine(kk, canon, genome, 0)
@@ -605,7 +629,7 @@ def main():
                                       MIN_COUNT, CHUNK_MIB, nchunks, "canonical" if canonical else "forward-strand"),
                        "reads_per_gpu": args.reads if mode == "weak" else args.reads / ngpu, "read_len": READ_LEN, "k": k,
                        "min_count": MIN_COUNT, "chunk_mib": CHUNK_MIB, "chunks": nchunks, "mode": st["mode_name"],
-                       "contexts_per_gpu": nctx, "parallelism": par},
+                       "contexts_per_gpu": nctx, "shared_table": eng.shared, "parallelism": par},
             "distinct_kmers_per_s": total_rows * args.steps / dt,
             "distinct_prefilter_per_s": st["distinct"] * world / dt,  # distinct keys per chunk, before the -c filter
             "rows": total_rows,

@@ -265,6 +265,13 @@ int mk_words_per_key(const mk_ctx* ctx);
  * contexts (= HIP streams) that count concurrently and sum them at the end, on the device. */
 int mk_merge_from(mk_ctx* dst, mk_ctx* src);
 
+/* Several contexts of ONE GPU, one running table (round 4): from now on the count kernels of ctx put the survivors of its
+ * chunks straight into owner's table (fused launches, one-word keys; whatever ctx still merges on its own -- a new
+ * context's first chunk, rows kept as text -- stays in ctx's table).  Sum as before at the end: mk_merge_from(owner, ctx)
+ * now finds little to add.  owner == NULL: ctx goes back to its own table.  Same GPU, alphabet, k, canonical mode; one
+ * level deep.  The caller orders mk_reset(owner) against the sharers' chunks (reset the owner first). */
+int mk_share_table(mk_ctx* ctx, mk_ctx* owner);
+
 /* ---- one process, several GPUs: the Ray fan-out of a sample's chunks over workers and the dict sum of their
  *      results (bin/mercat2.py:119-127, 336-339) with the workers being the GPUs of one node ------------- */
 /* Equal key ranges: bounds[i-1] = first key (first 64-bit word of the packed key, key_bits wide: bits*k for

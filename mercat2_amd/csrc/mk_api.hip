@@ -23,6 +23,8 @@ static size_t pow2_at_least(size_t v) {
   return p;
 }
 
+static void drain_table_users(mk_ctx* t);  // (mk_share_table, below)
+
 // ------------------------------------------------------------------------------ buffers
 int mk_buf_reserve(mk_ctx* c, MkDevBuf& b, size_t bytes, bool keep) {
   if (bytes <= b.cap) return MK_OK;
@@ -216,6 +218,8 @@ extern "C" void mk_destroy(mk_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->share_owner) (void)mk_share_table(c, nullptr);
+  for (mk_ctx* s : std::vector<mk_ctx*>(c->sharers)) (void)mk_share_table(s, nullptr);  // (their rows in this table go with it)
   for (auto& p : c->events) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto& e : c->event_pool) (void)hipEventDestroy(e);
   MkDevBuf* all[] = {&c->raw, &c->seq, &c->codes, &c->bad, &c->tile_maps, &c->info, &c->ctab, &c->rtab_chunk, &c->run,
@@ -236,6 +240,10 @@ static int reset_impl(mk_ctx* c, size_t expect_rows) {
   if (!c) return MK_ERR_ARG;
   MK_HIP(hipSetDevice(c->device));
   if (c->pending_rows) { MK_HIP(hipStreamSynchronize(c->stream)); c->pending_rows = false; }
+  // (a table other contexts launch into: nobody launches while it is cleared, and what was launched has finished.  The
+  // ORDER of a sharer's chunks against this reset is the caller's: reset the owner before the sharers count the next sample)
+  std::unique_lock<std::shared_mutex> table_lock(c->table_mu, std::defer_lock);
+  if (!c->sharers.empty()) { table_lock.lock(); drain_table_users(c); }
   if (expect_rows && c->mode != MK_MODE_DENSE) {
     const size_t want = pow2_at_least(4 * expect_rows);
     if (c->run_slots > want) c->run_slots = want;
@@ -334,6 +342,51 @@ extern "C" int mk_clean_runs(mk_ctx* c, uint64_t* starts, uint64_t* ends, size_t
   return MK_OK;
 }
 
+// ------------------------------------------------------------- one running table for several contexts of a GPU
+// The chunks of a sample are dealt to several contexts of one GPU (HIP streams: one's kernels fill the other's gaps), and
+// up to round 3 every context summed its survivors into a table of its own, the tables were summed table to table at
+// the end (canonical S2: ~1 ms of the step for the second context's 9.9 M rows).  With fused launches (mk_skcount.hip)
+// every access to a running table from a count kernel is an atomic, so the kernels of several streams can upsert into
+// ONE table.  mk_share_table(ctx, owner): from now on the fused launches of ctx put their survivors into owner's table;
+// whatever ctx still merges on its own (a new context's first chunk, spills, rows kept as text) stays in ctx's table and
+// is summed at the end as before (mk_merge_from), only it is small now.  Locking: a launch that uses a shared table
+// reads its pointer and size under the table's lock (shared); growing or clearing the table takes the lock exclusively,
+// waits for the streams of all contexts that launch into it, and only then replaces it.
+static int grow_run64(mk_ctx* c, size_t need_rows);
+static int grow_run64_body(mk_ctx* c, size_t need_rows);
+static mk_ctx* table_of_ctx(mk_ctx* c) { return c->share_owner ? c->share_owner : c; }
+
+static void drain_table_users(mk_ctx* t) {  // (t->table_mu is held exclusively: nobody can launch into the table meanwhile)
+  (void)hipStreamSynchronize(t->stream);
+  for (mk_ctx* s : t->sharers) (void)hipStreamSynchronize(s->stream);
+}
+
+extern "C" int mk_share_table(mk_ctx* c, mk_ctx* owner) {
+  if (!c || c == owner) return MK_ERR_ARG;
+  if (c->in_chunk) { c->err = "mk_share_table: a chunk is open"; return MK_ERR_STATE; }
+  if (c->share_owner == owner) return MK_OK;
+  if (c->share_owner) {  // leave the table it launched into
+    mk_ctx* old = c->share_owner;
+    std::unique_lock<std::shared_mutex> wr(old->table_mu);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    old->sharers.erase(std::remove(old->sharers.begin(), old->sharers.end(), c), old->sharers.end());
+    c->share_owner = nullptr;
+    c->fuse_target = nullptr;
+  }
+  if (!owner) return MK_OK;
+  if (owner->share_owner || !c->sharers.empty()) { c->err = "mk_share_table: tables are shared one level deep (the owner must own its table, a sharer cannot be an owner)"; return MK_ERR_ARG; }
+  if (owner->device != c->device || owner->alphabet != c->alphabet || owner->k != c->k || owner->canonical != c->canonical || owner->mode != c->mode) {
+    c->err = "mk_share_table: contexts differ in device, alphabet, k or canonical mode";
+    return MK_ERR_ARG;
+  }
+  if (c->mode != MK_MODE_HASH64) { c->err = "mk_share_table: only one-word hashed tables are shared"; return MK_ERR_ARG; }
+  std::unique_lock<std::shared_mutex> wr(owner->table_mu);
+  owner->sharers.push_back(c);
+  c->share_owner = owner;
+  return MK_OK;
+}
+
 // ----------------------------------------------------------------------------- chunk feed
 extern "C" int mk_chunk_begin(mk_ctx* c) {
   if (!c) return MK_ERR_ARG;
@@ -388,7 +441,16 @@ static size_t run_slots_for(size_t need_rows) {
   return pow2_at_least(x4 ? 4 * need_rows : need_rows * 5 / 2);
 }
 
+static int grow_run64_body(mk_ctx* c, size_t need_rows);
+// (a table other contexts launch into -- mk_share_table -- is only replaced under its lock, with their streams drained)
 static int grow_run64(mk_ctx* c, size_t need_rows) {
+  if (c->sharers.empty()) return grow_run64_body(c, need_rows);
+  std::unique_lock<std::shared_mutex> wr(c->table_mu);
+  if (2 * need_rows <= c->run_slots) return MK_OK;
+  drain_table_users(c);
+  return grow_run64_body(c, need_rows);
+}
+static int grow_run64_body(mk_ctx* c, size_t need_rows) {
   if (2 * need_rows <= c->run_slots) return MK_OK;
   const size_t slots = run_slots_for(need_rows);
   MkDevBuf nb;
@@ -483,11 +545,33 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     const int cap = per_bucket <= 110 ? 512 : (per_bucket <= 360 ? 1024 : 0);
     if (cap) {
       if ((rc = settle(c)) != MK_OK) return rc;  // (run_rows must be what the table holds)
-      if ((rc = grow_run64(c, c->run_rows + 2 * (size_t)c->surv_hint + 4096)) != MK_OK) return rc;
+      // Which table: the owner's when this context shares one (mk_share_table) AND that table has room for what this
+      // chunk is expected to add -- only the owner ever replaces its table (it sizes it for its sharers as well), a sharer
+      // that finds it too small upserts into its own for this chunk; the sum at the end is the same.
+      mk_ctx* t = table_of_ctx(c);
+      const size_t expect = 2 * (size_t)c->surv_hint + 4096;
+      if (t != c) {
+        std::shared_lock<std::shared_mutex> rd(t->table_mu);
+        size_t rows_now;
+        { std::lock_guard<std::mutex> g(t->rows_mu); rows_now = t->run_rows; }
+        if (t->run_slots < 1024 || 2 * (rows_now + expect) > t->run_slots) t = c;
+      }
+      if (t == c) {
+        size_t rows_now;
+        { std::lock_guard<std::mutex> g(c->rows_mu); rows_now = c->run_rows; }
+        if ((rc = grow_run64(c, rows_now + expect * (1 + c->sharers.size()))) != MK_OK) return rc;
+      }
+      c->fuse_target = t;
       c->fuse_cap = cap;
     }
   }
-  rc = two ? mk_launch_count_superkmer2(c, n, min_count) : mk_launch_count_superkmer(c, n, min_count);  // (seq_len <= n)
+  {
+    // (a launch into ANOTHER context's table reads its pointer and size under that table's lock: see mk_share_table)
+    mk_ctx* t = c->fuse_cap ? c->fuse_target : c;
+    std::shared_lock<std::shared_mutex> rd(t->table_mu, std::defer_lock);
+    if (t != c) rd.lock();
+    rc = two ? mk_launch_count_superkmer2(c, n, min_count) : mk_launch_count_superkmer(c, n, min_count);  // (seq_len <= n)
+  }
   c->fuse_cap = 0;
   if (rc) return rc;
   const bool fused = !two && c->fused_last;
@@ -538,7 +622,11 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   c->part_dirty = false;  // the count kernel ran to its end: every cursor is back at its region's start
   const bool fused_done = !two && c->fused_last;  // (of the launch that counted: the exact pass is never fused)
   if (fused_done) {
-    c->run_rows += (size_t)h->new_rows;  // (counted by the kernel, in the same read-back)
+    {
+      mk_ctx* t = c->fuse_target ? c->fuse_target : c;  // (counted by the kernel, in the same read-back; the table may be another context's)
+      std::lock_guard<std::mutex> g(t->rows_mu);
+      t->run_rows += (size_t)h->new_rows;
+    }
     h->new_rows = 0;
     c->st.fused_chunks += 1;
     c->st.fuse_spilled += h->spilled;

@@ -182,6 +182,7 @@ struct mk_ctx {
   bool surv_hint_ok = false;
   // one table for several contexts of a device (mk_share_table): the fused launches of this context upsert into the owner's
   mk_ctx* share_owner = nullptr;
+  mk_ctx* fuse_target = nullptr;      // the context whose table the NEXT / last fused launch of this one upserts into (this or share_owner)
   std::vector<mk_ctx*> sharers;       // contexts whose fused launches upsert into THIS context's table
   std::shared_mutex table_mu;         // shared: a launch reads run.p / run_slots; exclusive: the table is replaced (grown) or cleared
   std::mutex rows_mu;                 // run_rows of an owner is added to by its sharers' host threads

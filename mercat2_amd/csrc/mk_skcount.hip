@@ -139,7 +139,7 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
 // is still in flight when the workgroup runs out of buckets is finished in a loop.  The host sizes the table BEFORE the
 // launch from the previous chunk's survivors; an entry that has probed SKF_MAX_PROBE slots (a table filling up: the
 // estimate was far off) is written to the spill list instead (the old survivor buffer) and imported by the host afterwards.
-#define SKF_MAX_PROBE 96
+#define SKF_MAX_PROBE 96  // (default of the kernels' max_probe argument; MK_FUSE_MAX_PROBE lowers it: tests of the spill path)
 __device__ __forceinline__ void skf_spill(MkChunkInfo* info, u64* sp_keys, u64* sp_cnts, u64 key, unsigned cnt) {
   const u64 at = atomicAdd(&info->spilled, 1ull);
   sp_keys[at] = key;
@@ -147,14 +147,14 @@ __device__ __forceinline__ void skf_spill(MkChunkInfo* info, u64* sp_keys, u64* 
 }
 // `old` = what the compare-and-swap at `slot` returned; probes on (with waits) until the key has a slot
 __device__ __forceinline__ void skf_finish(MkSlot* __restrict__ run, u64 mask, u64 key, unsigned cnt, u64 slot, u64 old, u64& fresh,
-                                           MkChunkInfo* info, u64* sp_keys, u64* sp_cnts) {
-  for (int probe = 0;; ++probe) {
+                                           MkChunkInfo* info, u64* sp_keys, u64* sp_cnts, unsigned max_probe) {
+  for (unsigned probe = 0;; ++probe) {
     if (old == MK_EMPTY || old == key) {
       atomicAdd(&run[slot].cnt, (u64)cnt);
       fresh += old == MK_EMPTY ? 1 : 0;
       return;
     }
-    if (probe >= SKF_MAX_PROBE) { skf_spill(info, sp_keys, sp_cnts, key, cnt); return; }
+    if (probe >= max_probe) { skf_spill(info, sp_keys, sp_cnts, key, cnt); return; }
     slot = (slot + 1) & mask;
     old = atomicCAS(&run[slot].key, MK_EMPTY, key);
   }
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
                                                              int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
-                                                             int dflags, MkSlot* __restrict__ run, u64 run_mask) {
+                                                             int dflags, MkSlot* __restrict__ run, u64 run_mask, unsigned max_probe) {
   constexpr bool FUSED = FCAP > 0;
   // (the longer list takes its LDS from the deferred-key stacks: two slots pushed at a time instead of four, measured 1 % slower)
   constexpr int PUSH = FCAP > 512 ? 2 : SKC_PUSH;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             fresh += f_old == MK_EMPTY ? 1 : 0;
           } else {
             const unsigned nslot = (slot + 1) & run_mask32;
-            if (((nslot - (unsigned)mk_mix64(key)) & run_mask32) > SKF_MAX_PROBE) {
+            if (((nslot - (unsigned)mk_mix64(key)) & run_mask32) > max_probe) {
               skf_spill(info, out_keys, out_cnts, key, cnt);
             } else {
               const unsigned pos = atomicAdd(&s_npend[f_cur ^ 1], 1u);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                 pend_cnt[f_cur ^ 1][pos] = cnt;
                 pend_slot[f_cur ^ 1][pos] = nslot;
               } else {  // (the list is full: this one waits for its answers)
-                skf_finish(run, run_mask, key, cnt, nslot, atomicCAS(&run[nslot].key, MK_EMPTY, key), fresh, info, out_keys, out_cnts);
+                skf_finish(run, run_mask, key, cnt, nslot, atomicCAS(&run[nslot].key, MK_EMPTY, key), fresh, info, out_keys, out_cnts, max_probe);
               }
             }
           }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                   pend_cnt[f_cur ^ 1][pos0 + o] = ec[q];
                   pend_slot[f_cur ^ 1][pos0 + o] = home;
                 } else {  // (more survivors than the list takes: rare by the host's choice of FCAP; exact, with waits)
-                  skf_finish(run, run_mask, key, ec[q], home, atomicCAS(&run[home].key, MK_EMPTY, key), fresh, info, out_keys, out_cnts);
+                  skf_finish(run, run_mask, key, ec[q], home, atomicCAS(&run[home].key, MK_EMPTY, key), fresh, info, out_keys, out_cnts, max_probe);
                 }
                 ++o;
               }
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   if (FUSED) {  // what is still in flight: finished here, with waits
     if (threadIdx.x < f_n)
       skf_finish(run, run_mask, pend_key[f_cur][threadIdx.x], pend_cnt[f_cur][threadIdx.x], (u64)pend_slot[f_cur][threadIdx.x], f_old, fresh,
-                 info, out_keys, out_cnts);
+                 info, out_keys, out_cnts, max_probe);
     for (int d = 32; d > 0; d >>= 1) fresh += __shfl_down(fresh, d);
     if (lane == 0 && fresh) atomicAdd(&s_fresh, (unsigned long long)fresh);
   }
@@ -1006,7 +1006,7 @@ int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64*
   hipLaunchKernelGGL((mk_sk_count_k<CANON, K32, FCAP>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
                      (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
                      (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf, dflags, \
-                     (MkSlot*)c->run.p, (u64)(c->run_slots ? c->run_slots - 1 : 0))
+                     (MkSlot*)tab->run.p, (u64)(tab->run_slots ? tab->run_slots - 1 : 0), max_probe)
 #define SKC_LAUNCH2(CANON, K32)                                                                                         \
   do {                                                                                                                  \
     if (fcap > 512) SKC_LAUNCH(CANON, K32, 1024);                                                                       \
@@ -1014,7 +1014,9 @@ int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64*
     else SKC_LAUNCH(CANON, K32, 0);                                                                                     \
   } while (0)
     // (fused: the survivors go straight into the running table, which process_chunk_fast has sized for them)
-    const int fcap = (c->fuse_cap > 0 && c->run_slots >= 1024 && c->run_slots <= ((size_t)1 << 32)) ? c->fuse_cap : 0;
+    const unsigned max_probe = getenv("MK_FUSE_MAX_PROBE") ? (unsigned)atoi(getenv("MK_FUSE_MAX_PROBE")) : (unsigned)SKF_MAX_PROBE;
+    mk_ctx* tab = (c->fuse_cap > 0 && c->fuse_target) ? c->fuse_target : c;  // (mk_share_table: the caller holds that table's lock)
+    const int fcap = (c->fuse_cap > 0 && tab->run_slots >= 1024 && tab->run_slots <= ((size_t)1 << 32)) ? c->fuse_cap : 0;
     c->fused_last = fcap > 0;
     if (c->canonical) { if (k == 32) SKC_LAUNCH2(true, true); else SKC_LAUNCH2(true, false); }
     else { if (k == 32) SKC_LAUNCH2(false, true); else SKC_LAUNCH2(false, false); }

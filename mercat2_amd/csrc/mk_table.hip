@@ -170,6 +170,9 @@ __device__ __forceinline__ bool upsert64_distinct(MkSlot* __restrict__ table, co
 }
 
 // Survivors laid out per bucket: bucket b holds nsurv[b] pairs from kstart[b] on. One wave per bucket.
+// ATOMIC: the counts are added with atomics -- for a table that other contexts' count kernels upsert into at the same
+// time (mk_share_table); otherwise the plain-store form above.
+template <bool ATOMIC>
 __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, const u64* __restrict__ kstart,
                                     const u64* __restrict__ nsurv, size_t p1, MkSlot* __restrict__ run, RunAddr run_mask,
                                     u64* __restrict__ new_rows) {
@@ -177,11 +180,8 @@ __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __r
   const int lane = threadIdx.x & 63;
   for (size_t b = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < p1; b += (size_t)gridDim.x * (blockDim.x >> 6)) {
     const u64 base = kstart[b], n = nsurv[b];
-#ifdef MK_IMPORT_ATOMIC  // (A/B builds: the add as an atomic, as before round 3)
-    for (u64 i = lane; i < n; i += 64) fresh += upsert64(run, run_mask, keys[base + i], cnts[base + i]) ? 1 : 0;
-#else
-    for (u64 i = lane; i < n; i += 64) fresh += upsert64_distinct(run, run_mask, keys[base + i], cnts[base + i]) ? 1 : 0;
-#endif
+    if (ATOMIC) { for (u64 i = lane; i < n; i += 64) fresh += upsert64(run, run_mask, keys[base + i], cnts[base + i]) ? 1 : 0; }
+    else { for (u64 i = lane; i < n; i += 64) fresh += upsert64_distinct(run, run_mask, keys[base + i], cnts[base + i]) ? 1 : 0; }
   }
   block_add(new_rows, fresh);
 }
@@ -194,9 +194,15 @@ int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* 
   // Many survivors per bucket (-c 1, canonical keys: a bucket keeps a thousand keys, each upsert is two dependent
   // round trips to HBM): every bucket gets its own wave at once -- the kernel is bound by requests in flight.
   const unsigned cap = survivors > 64 * p1 ? 4096u : 512u;
-  hipLaunchKernelGGL(mk_import_regions_k, dim3(grid_for(p1 * 64, 256, cap)), dim3(256), 0, c->stream, (const u64*)d_keys,
-                     (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
-                     run_addr(c, c->run_slots), &info->new_rows);
+  static const bool always_atomic = getenv("MK_IMPORT_ATOMIC") != nullptr;  // (A/B: the add as an atomic, as before round 3)
+  if (always_atomic || !c->sharers.empty())
+    hipLaunchKernelGGL(mk_import_regions_k<true>, dim3(grid_for(p1 * 64, 256, cap)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                       (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
+                       run_addr(c, c->run_slots), &info->new_rows);
+  else
+    hipLaunchKernelGGL(mk_import_regions_k<false>, dim3(grid_for(p1 * 64, 256, cap)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                       (const u64*)d_counts, (const u64*)kstart, (const u64*)nsurv, p1, (MkSlot*)c->run.p,
+                       run_addr(c, c->run_slots), &info->new_rows);
   MK_HIP(hipGetLastError());
   return MK_OK;
 }

@@ -59,6 +59,7 @@ def _take_context(k: int, alphabet: int, device: int, canonical: bool) -> native
 def _give_back(ctx: native.Counter, key, text_bytes: int) -> None:
     if text_bytes < (1 << 62):  # (1 << 62: the context saw an error, or its sample was not finished)
         try:
+            ctx.share_table(None)
             ctx.reset()
             ctx.reset_stats()
             with _POOL_LOCK:
@@ -96,7 +97,18 @@ def _take_contexts(kmer: int, alphabet: int, devs: Sequence[int], streams: int, 
     """Contexts in the order mk_count_file wants them (native.plan_contexts): chunk i -> device devs[i mod ndev],
     the chunks of a device taking turns on its ``streams`` contexts; at most ``limit`` contexts (chunks of the sample)."""
     order = native.plan_contexts(list(devs), max(1, int(streams)))[: max(1, limit)]
-    return [_take_context(kmer, alphabet, d, canon) for d in order]
+    ctxs = [_take_context(kmer, alphabet, d, canon) for d in order]
+    # the contexts of one GPU upsert their chunks' survivors into ONE running table, the first one's (mk_share_table:
+    # one-word hashed tables; the sum at the end of the sample then finds little left to add)
+    first = {}
+    for c in ctxs:
+        lead = first.setdefault(c.device, c)
+        if lead is not c:
+            try:
+                c.share_table(lead)
+            except native.MercatHipError:
+                pass  # (other table kinds: every context keeps its own, as before)
+    return ctxs
 
 
 def _sum_into_first(ctxs: Sequence[native.Counter]) -> None:

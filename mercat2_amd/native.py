@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "mk_owner_bounds", "mk_plan_contexts", "mk_bucket_rows_device", "mk_import_rows_device", "mk_merge_devices",
     "mk_export_size_multi", "mk_export_multi", "mk_write_tsv_multi", "mk_record_cuts", "mk_sample_keys", "mk_dense_bins_device",
     "mk_device_count", "mk_reset_for", "mk_textwrap", "mk_set_clean", "mk_clean_stats", "mk_clean_runs",
-    "mk_export_stats",
+    "mk_export_stats", "mk_share_table",
 ]
 MK_ABI = 4  # the number mk_version() must announce: struct layouts and signatures of include/mercat_hip.h as bound below
 MERGE_RANGES, MERGE_GATHER, MERGE_BALANCED, MERGE_RCCL = 0, 1, 2, 4
@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
         "mk_import_exotic": (C.c_int, [vp, u8p, u64p, C.c_size_t]),
         "mk_words_per_key": (C.c_int, [vp]),
         "mk_merge_from": (C.c_int, [vp, vp]),
+        "mk_share_table": (C.c_int, [vp, vp]),
         "mk_set_profiling": (C.c_int, [vp, C.c_int]),
         "mk_get_stats": (C.c_int, [vp, C.POINTER(Stats)]),
         "mk_reset_stats": (C.c_int, [vp]),
@@ -660,6 +661,11 @@ class Counter:
     def merge_from(self, other: "Counter"):
         """Add every row of ``other`` (same GPU, alphabet, k) into this context, on the device."""
         self._check(self._L.mk_merge_from(self._h, other._h))
+
+    def share_table(self, owner: Optional["Counter"]):
+        """From now on this context's count kernels put the survivors of its chunks into ``owner``'s running table (same
+        GPU, alphabet, k; mk_share_table); ``None``: back to its own.  Sum with ``owner.merge_from(self)`` as before."""
+        self._check(self._L.mk_share_table(self._h, owner._h if owner is not None else None))
 
     def export_exotic(self) -> Tuple[np.ndarray, np.ndarray]:
         n = C.c_size_t(0)

@@ -88,6 +88,62 @@ def test_merge_devices_equals_the_oracle(k, c, alphabet, n, flags):
             x.close()
 
 
+@pytest.mark.parametrize("k,c,canonical", [(31, 2, False), (21, 3, False), (31, 2, True), (32, 2, False)])
+def test_contexts_of_one_gpu_share_a_running_table(k, c, canonical):
+    """mk_share_table: three contexts (streams) of the one GPU count the chunks of a sample side by side, each from a
+    host thread of its own, and their count kernels upsert the survivors into ONE table -- the first context's; what a
+    context still merges on its own (its first chunk, when it is new) is summed at the end as before.  Two samples one
+    after the other through the same contexts (the second finds the tables sized and every chunk fused), then the
+    contexts go back to tables of their own.  Equal to the oracle's chunk-by-chunk sum every time."""
+    from concurrent.futures import ThreadPoolExecutor
+    from mercat2_amd.chunker import chunk_offsets
+    from oracle import c_oracle
+    n = 3
+    ctxs = [native.Counter(k, native.ALPHABET_NT2, device=0, canonical=canonical) for _ in range(n)]
+    try:
+        for x in ctxs[1:]:
+            x.share_table(ctxs[0])
+        with pytest.raises(native.MercatHipError):
+            ctxs[0].share_table(ctxs[1])  # one level deep
+        for seed in (51, 53):
+            data = native.synth_reads(80_000, seed, 90_000, 150, seed + 1).tobytes()
+            offs = chunk_offsets(data, 1_500_000)
+            spans = list(zip(offs[:-1], offs[1:]))
+            assert len(spans) >= 8
+            parts = [c_oracle.count_dict(data[a:b], k, 0 if canonical else c) for a, b in spans]
+            if canonical:
+                parts = [{key: m for key, m in cpu_ref.canonical_fold(p).items() if m >= c} for p in parts]
+            want = cpu_ref.merge_counts(parts)
+            for x in ctxs:  # (the owner is reset before anybody counts into its table again)
+                x.reset()
+
+            def share(i):
+                for a, b in spans[i::n]:
+                    ctxs[i].count_chunk(memoryview(data)[a:b], c)
+            with ThreadPoolExecutor(n) as pool:
+                list(pool.map(share, range(n)))
+            fused = [x.stats()["fused_chunks"] for x in ctxs]
+            for x in ctxs[1:]:
+                ctxs[0].merge_from(x)
+            assert ctxs[0].to_dict() == want, (seed, fused)
+            if seed == 53:  # (second sample: hints and table sizes are there, the sharers' rows are in the owner's table)
+                assert all(x.rows() < len(want) // 4 for x in ctxs[1:]), [x.rows() for x in ctxs]
+        for x in ctxs[1:]:
+            x.share_table(None)
+        data = native.synth_reads(80_000, 57, 30_000, 150, 58).tobytes()
+        for x in ctxs:
+            x.reset()
+            x.reset_stats()
+        ctxs[1].count_chunk(data, c)
+        got = c_oracle.count_dict(data, k, 0 if canonical else c)
+        if canonical:
+            got = {key: m for key, m in cpu_ref.canonical_fold(got).items() if m >= c}
+        assert ctxs[1].to_dict() == got and ctxs[0].rows() == 0
+    finally:
+        for x in ctxs:
+            x.close()
+
+
 def test_balanced_bounds_even_out_a_skewed_table():
     """Keys crowded into the low half of the key space (sequences over A and C only: every key starts with the bits
     00 or 01): equal key ranges leave two of four owners empty, sampled splitters share the rows out."""

@@ -627,6 +627,55 @@ def test_blanks_in_header_lines_keep_the_fast_parser():
         assert ctx.stats()["parse_retries"] == 2
 
 
+@pytest.mark.parametrize("canonical", [False, True])
+def test_fused_upsert_paths_are_exact(monkeypatch, canonical):
+    """The count kernel's own merge into the running table (mk_skcount.hip, FCAP > 0) against the regions + import kernel
+    it replaces, on chunks of one sample (the second chunk on is a fused launch), and its two side doors: (a) the spill
+    list -- MK_FUSE_MAX_PROBE=0 sends every survivor whose first slot holds another key there, the host imports it
+    afterwards; (b) the blocking finish of survivors that do not fit a sweep's list -- a bucket of a small chunk with
+    -c 1... -c 2 on a tiny genome keeps far more than 512 keys.  All three equal the oracle; the counters say which ran."""
+    from oracle import c_oracle
+    data = native.synth_reads(60_000, 21, 120_000, 150, 22).tobytes()
+    offs = chunk_offsets(data, 4_000_000)
+    assert len(offs) > 4
+    spans = list(zip(offs[:-1], offs[1:]))
+
+    def want(c):
+        parts = [c_oracle.count_dict(data[a:b], 31, 0 if canonical else c) for a, b in spans]
+        if canonical:
+            parts = [_fold_filter(p, c) for p in parts]
+        return cpu_ref.merge_counts(parts)
+
+    def run(c):
+        with native.Counter(31, native.ALPHABET_NT2, canonical=canonical) as ctx:
+            for a, b in spans:
+                ctx.count_chunk(memoryview(data)[a:b], c)
+            return ctx.to_dict(), ctx.stats()
+    for c in (2, 3):
+        got, st = run(c)
+        assert got == want(c) and st["fused_chunks"] == len(spans) - 1 and st["fuse_spilled"] == 0, (c, st)
+    monkeypatch.setenv("MK_FUSE_MAX_PROBE", "0")
+    got, st = run(2)
+    assert got == want(2) and st["fused_chunks"] == len(spans) - 1 and st["fuse_spilled"] > 1000, st
+    monkeypatch.delenv("MK_FUSE_MAX_PROBE")
+    monkeypatch.setenv("MK_NO_FUSE", "1")
+    # (read when a context is created)
+    got, st = run(2)
+    assert got == want(2) and st["fused_chunks"] == 0
+    monkeypatch.delenv("MK_NO_FUSE")
+    # (b): small chunks have 256 buckets; every k-mer of the 60 kbp genome survives -c 2 in every chunk: ~470 survivors per
+    # bucket forward, twice that many canonical keys per bucket when both strands fold -- beyond the 512-entry list
+    with native.Counter(31, native.ALPHABET_NT2, canonical=canonical) as ctx:
+        small = chunk_offsets(data, 1_000_000)
+        for a, b in zip(small[:-1], small[1:]):
+            ctx.count_chunk(memoryview(data)[a:b], 2)
+        parts = [c_oracle.count_dict(data[a:b], 31, 0 if canonical else 2) for a, b in zip(small[:-1], small[1:])]
+        if canonical:
+            parts = [_fold_filter(p, 2) for p in parts]
+        assert ctx.to_dict() == cpu_ref.merge_counts(parts)
+        assert ctx.stats()["fused_chunks"] == len(small) - 2
+
+
 def test_long_lines_and_long_headers():
     """A 3 Mbp record on ONE line, a 200 kB header, and 70 kB of text in front of the first header:
     lines far longer than a parser wave (4 KiB) or workgroup."""
