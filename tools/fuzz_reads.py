@@ -36,8 +36,20 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
             table = c_oracle.count_dict(data[a:b], k, c)
         for key, n in table.items():
             want[key] = want.get(key, 0) + n
-    ctxs = [native.Counter(k, native.ALPHABET_NT2, canonical=CANON) for _ in range(rng.choice([1, 2]))]
+    ctxs = [native.Counter(k, native.ALPHABET_NT2, canonical=CANON) for _ in range(rng.choice([1, 2, 3]))]
+    shared = False
+    if len(ctxs) > 1 and k <= 32 and rng.random() < 0.6:  # one running table for the contexts (mk_share_table)
+        for x in ctxs[1:]:
+            x.share_table(ctxs[0])
+        shared = True
     try:
+        if rng.random() < 0.5:  # a first sample through the same contexts: hints and table sizes from another text
+            other = native.synth_reads(rng.choice([40_000, 3_000_000]), rng.randrange(1 << 30), 100_000, 150, rng.randrange(1 << 30)).tobytes()
+            p2 = os.path.join(d, "w%d.fna" % case)
+            open(p2, "wb").write(other)
+            native.count_file(ctxs, p2, 4 << 20, rng.choice([1, 2, 10]))
+            for x in ctxs:
+                x.reset()
         st = native.count_file(ctxs, path, size, c)
         got = ctxs[0].to_dict()
         retries = sum(x.stats()["part_retries"] for x in ctxs)
@@ -45,8 +57,8 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
         for x in ctxs:
             x.close()
     ok = got == want
-    print("case %d: genome %d reads %d sub %d k %d c %d -s %d: %d chunks, %d rows, retries %d, %s" % (
-        case, genome, reads, sub, k, c, mib, st["chunks"], len(got), retries, "ok" if ok else "MISMATCH"), flush=True)
+    print("case %d: genome %d reads %d sub %d k %d c %d -s %d ctxs %d%s: %d chunks, %d rows, retries %d, %s" % (
+        case, genome, reads, sub, k, c, mib, len(ctxs), " shared" if shared else "", st["chunks"], len(got), retries, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)
 print("all ok")
