@@ -731,7 +731,7 @@ def single_process_leg(args, backend):
     for label, extra in (("peer_copies", []), ("rccl", ["--merge-rccl"])):
         t0 = time.perf_counter()
         try:
-            p = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.rank_timeout)
+            p = subprocess.run(cmd + extra, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=min(args.rank_timeout, 300))
             lines = [ln for ln in p.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 out[label] = {"error": "exit %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
@@ -741,7 +741,7 @@ def single_process_leg(args, backend):
                                                       "merge_devices", "per_rank", "steps", "warmup")}
             out[label]["wall_s"] = time.perf_counter() - t0
         except subprocess.TimeoutExpired:
-            out[label] = {"error": "no line within --rank-timeout %d s (the child was killed)" % args.rank_timeout}
+            out[label] = {"error": "no line within %d s (the child was killed)" % min(args.rank_timeout, 300)}
         except (OSError, ValueError) as e:
             out[label] = {"error": repr(e)[:300]}
     out["note"] = "one process drives all GPUs through the C ABI (mk_count_device per chunk, mk_merge_devices, mk_export per " \

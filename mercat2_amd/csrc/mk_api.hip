@@ -541,7 +541,8 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
   // kept, twice over; the kernel spills what a table that fills up all the same cannot take, and that is imported below.
   c->fuse_cap = 0;
   if (!two && c->use_fused && min_count >= 2 && c->surv_hint_ok && !c->run_bucket_major) {
-    const unsigned long long per_bucket = c->surv_hint >> 13;  // (8192 buckets on chunks of this size; smaller chunks: fewer of both)
+    static const bool cores = getenv("MK_CORES") != nullptr;  // (half-sized buckets: half the survivors per bucket, half the list)
+    const unsigned long long per_bucket = (c->surv_hint >> 13) * (cores ? 2 : 1);  // (8192 buckets on chunks of this size; smaller chunks: fewer of both)
     const int cap = per_bucket <= 110 ? 512 : (per_bucket <= 360 ? 1024 : 0);
     if (cap) {
       if ((rc = settle(c)) != MK_OK) return rc;  // (run_rows must be what the table holds)

@@ -251,6 +251,9 @@ void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned
 // mk_skcount.hip: the count kernel of the one-word super-k-mer path over the bucket regions the scatter filled
 int mk_launch_sk_count(mk_ctx* c, const unsigned long long* start, unsigned* cursor, const unsigned long long* kstart,
                        unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact);
+// mk_skcount_small.hip: the same with 512-thread workgroups and 4096-slot tables (experiment MK_CORES)
+int mk_launch_sk_count_small(mk_ctx* c, const unsigned long long* start, unsigned* cursor, const unsigned long long* kstart,
+                             unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,

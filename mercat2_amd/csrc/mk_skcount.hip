@@ -9,6 +9,18 @@
 #include <vector>
 #include <type_traits>
 
+#ifdef SKC_SMALL  // (mk_skcount_small.hip: this file once more with 512 threads / 4096 slots, under names of its own)
+#define mk_sk_count_k mk_sk_count_small_k
+#define mk_sk_countp_k mk_sk_countp_small_k
+#define mk_launch_sk_count mk_launch_sk_count_small
+#define mk_dbg_ptr mk_dbg_ptr_small
+#define SKC_FCAP_A 256   // list entries per sweep of the fused upsert: the short and the long list
+#define SKC_FCAP_B 512
+#else
+#define SKC_FCAP_A 512
+#define SKC_FCAP_B 1024
+#endif
+
 #ifndef SKC_SLOTS
 #define SKC_SLOTS 8192          // LDS table slots of one workgroup (12 bytes each)
 #endif
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                                                              int dflags, MkSlot* __restrict__ run, u64 run_mask, unsigned max_probe) {
   constexpr bool FUSED = FCAP > 0;
   // (the longer list takes its LDS from the deferred-key stacks: two slots pushed at a time instead of four, measured 1 % slower)
-  constexpr int PUSH = FCAP > 512 ? 2 : SKC_PUSH;
+  constexpr int PUSH = FCAP > SKC_FCAP_A ? 2 : SKC_PUSH;
   constexpr int QCAP = 64 + 64 * PUSH;
 #ifdef SKC_UNCOND
   __shared__ __attribute__((aligned(16))) u64 tkey[SKC_SLOTS + 64];  // (+ a word per lane for the swaps of lanes without a key)
@@ -1009,8 +1021,8 @@ int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64*
                      (MkSlot*)tab->run.p, (u64)(tab->run_slots ? tab->run_slots - 1 : 0), max_probe)
 #define SKC_LAUNCH2(CANON, K32)                                                                                         \
   do {                                                                                                                  \
-    if (fcap > 512) SKC_LAUNCH(CANON, K32, 1024);                                                                       \
-    else if (fcap > 0) SKC_LAUNCH(CANON, K32, 512);                                                                     \
+    if (fcap > 512) SKC_LAUNCH(CANON, K32, SKC_FCAP_B);                                                                 \
+    else if (fcap > 0) SKC_LAUNCH(CANON, K32, SKC_FCAP_A);                                                              \
     else SKC_LAUNCH(CANON, K32, 0);                                                                                     \
   } while (0)
     // (fused: the survivors go straight into the running table, which process_chunk_fast has sized for them)

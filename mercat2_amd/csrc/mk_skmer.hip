@@ -48,9 +48,11 @@
 #define SK_SCAT_SUBT 2
 #endif
 #ifndef SK_MAX_P1_LOG2
-#define SK_MAX_P1_LOG2 13
+#define SK_MAX_P1_LOG2 14       // most buckets a chunk is cut into (2^13 by default: the launcher's choice; 2^14 with MK_CORES)
 #endif
 #define SK_MAX_P1 (1 << SK_MAX_P1_LOG2)
+#define SK_LH_LOG2 13           // bucket counters the queue scatter keeps in LDS at a time: with more buckets than that a tile
+#define SK_LH (1 << SK_LH_LOG2) // is worked off in rounds of 2^13 buckets (the LDS stays at 72-80 KB: two workgroups per CU)
 #ifndef SK_BUCKET_SYMS
 #define SK_BUCKET_SYMS 8192     // symbols of the chunk per bucket the bucket count aims at (~1.2K records, ~10K windows)
 #endif
@@ -87,9 +89,10 @@ __global__ __launch_bounds__(SK_HIST_THREADS) void mk_sk_hist_k(const u64* __res
                                                                 const MkChunkInfo* __restrict__ info, u64* __restrict__ hist,
                                                                 u64* __restrict__ khist, int p1_log2, int k, int nkmax,
                                                                 size_t nthreads_total, int canon, int sample_log2) {
-  __shared__ unsigned lh[SK_MAX_P1];  // records per bucket
-  __shared__ unsigned lk[SK_MAX_P1];  // k-mers per bucket (bounds the bucket's survivors)
+  extern __shared__ unsigned sk_hist_lds[];  // 2 x p1 words (launcher): records per bucket, then k-mers per bucket
   const unsigned p1 = 1u << p1_log2;
+  unsigned* const lh = sk_hist_lds;        // records per bucket
+  unsigned* const lk = sk_hist_lds + p1;   // k-mers per bucket (bounds the bucket's survivors)
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) { lh[i] = 0; lk[i] = 0; }
   __syncthreads();
   const size_t seq_len = info->seq_len;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                                                          MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                          SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                          int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap) {
-  __shared__ unsigned lh[SK_MAX_P1];  // as above: counts, then base + rank
+  __shared__ unsigned lh[SK_LH];  // as above: counts, then base + rank -- of the 2^13 buckets of the current round
   // every thread's first word; its second is the next lane's first, and a wave keeps the second word of its last lane
   // itself (pass 1 runs between wave barriers only: a wave must not read what another wave writes)
   __shared__ u64 pk_x[SKQ_SUBT][SKQ_WAVES][65];
@@ -346,11 +349,13 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   __syncthreads();
   if (s_abort) return;  // the regions do not fit the buffers: nothing may be written
   unsigned spilled = 0;
-  constexpr int NB = SK_MAX_P1 / SKQ_THREADS;
+  constexpr int NB = SK_LH / SKQ_THREADS;
   const unsigned p1 = 1u << p1_log2;
+  const unsigned lhn = p1 < (unsigned)SK_LH ? p1 : (unsigned)SK_LH;  // counters in use
+  const unsigned nround = p1 / lhn;                                  // 1, or 2 with 2^14 buckets
   const size_t seq_len = info->seq_len;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+  for (unsigned i = threadIdx.x; i < lhn; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, ntile = 0;
   (void)tA; (void)tB; (void)tC; (void)tD; (void)tE; (void)tF; (void)t0; (void)ntile;
@@ -411,42 +416,78 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #else
             const unsigned b = sk_bucket(mm, p1_log2);
 #endif
-            atomicAdd(&lh[b], 1u);
+            if ((b >> SK_LH_LOG2) == 0) atomicAdd(&lh[b & (SK_LH - 1)], 1u);  // (round 0's buckets: counted as they are found)
             myq[i] = (it & 0xFFFFu) | (b << 16);
           }
         }
         qn[st] = total;
       } else {
         if (p0 < seq_len)
-          sk_walk(runs, ww0, ww1, nkmax, CANON, [&](int, int, unsigned mm) { atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u); });
+          sk_walk(runs, ww0, ww1, nkmax, CANON, [&](int, int, unsigned mm) {
+            const unsigned b = sk_bucket(mm, p1_log2);
+            if ((b >> SK_LH_LOG2) == 0) atomicAdd(&lh[b & (SK_LH - 1)], 1u);
+          });
         qn[st] = SKQ_WALKED;
+      }
+    }
+    // A tile's records are placed in rounds of 2^13 buckets (one round unless the chunk is cut into 2^14): count the
+    // round's records per bucket (round 0: done above), reserve their runs, store them, clear the counters.
+#pragma unroll 1
+    for (unsigned round = 0; round < nround; ++round) {
+    SkCursor* const rcursor = cursor + (size_t)round * SK_LH;
+    const u64* const rstart = start + (size_t)round * SK_LH;
+    if (round) {
+#pragma unroll
+      for (int st = 0; st < SKQ_SUBT; ++st) {
+        if (qn[st] != SKQ_WALKED) {
+          const unsigned total = qn[st];
+          const unsigned* const myq = queue[st][wv];
+          for (unsigned base = 0; base < total; base += 64) {
+            const unsigned i = base + lane;
+            if (i < total) {
+              const unsigned b = myq[i] >> 16;
+              if ((b >> SK_LH_LOG2) == round) atomicAdd(&lh[b & (SK_LH - 1)], 1u);
+            }
+          }
+        } else {
+          const size_t t = (tile * SKQ_SUBT + st) * SKQ_THREADS + threadIdx.x;
+          const size_t p0 = t * SK_R;
+          if (p0 < seq_len) {
+            const ulonglong2 w = make_ulonglong2(pk_x[st][wv][lane], pk_x[st][wv][lane + 1]);
+            const SkRuns runs = sk_analyse<W>(w.x, w.y, sk_valid32(bad_window(bad, p0), k), CANON);
+            sk_walk(runs, w.x, w.y, nkmax, CANON, [&](int, int, unsigned mm) {
+              const unsigned b = sk_bucket(mm, p1_log2);
+              if ((b >> SK_LH_LOG2) == round) atomicAdd(&lh[b & (SK_LH - 1)], 1u);
+            });
+          }
+        }
       }
     }
     STAMP_ADD(tA, t0);
     __syncthreads();
     STAMP_ADD(tB, t0);
 #ifndef SK_PLAIN_CURSORS
-    if (p1 == SK_MAX_P1) {  // (8192 buckets, 8 per thread: all reservations in flight together, mk_skmer_dev.h)
+    if (lhn == SK_LH) {  // (8192 buckets, 8 per thread: all reservations in flight together, mk_skmer_dev.h)
       static_assert(NB % 8 == 0, "sk_reserve8");
 #pragma unroll
       for (int h = 0; h < NB; h += 8) {  // (512 threads: buckets 0..4095, then 4096..8191)
         unsigned v[8], at[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = lh[threadIdx.x + (h + i) * SKQ_THREADS];
-        spilled |= sk_reserve8<SKQ_THREADS>(v, cursor + h * SKQ_THREADS, start + h * SKQ_THREADS, SK_NOFIT, at);
+        spilled |= sk_reserve8<SKQ_THREADS>(v, rcursor + h * SKQ_THREADS, rstart + h * SKQ_THREADS, SK_NOFIT, at);
 #pragma unroll
         for (int i = 0; i < 8; ++i) lh[threadIdx.x + (h + i) * SKQ_THREADS] = at[i];
       }
     } else
 #endif
     {  // (fewer buckets than the most -- small chunks: a plain loop, one bucket at a time)
-      for (unsigned b = threadIdx.x; b < p1; b += SKQ_THREADS) {
+      for (unsigned b = threadIdx.x; b < lhn; b += SKQ_THREADS) {
         const unsigned v = lh[b];
-        const u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
+        const u64 r = v ? (u64)atomicAdd(&rcursor[b], v) : 0ull;
 #ifdef SK_ABL_COARSE
-        const bool fits = v == 0 || r + v <= start[b + 64 < p1 ? b + 64 : p1];
+        const bool fits = v == 0 || r + v <= rstart[b + 64 < p1 ? b + 64 : p1];
 #else
-        const bool fits = v == 0 || r + v <= start[b + 1];
+        const bool fits = v == 0 || r + v <= rstart[b + 1];
 #endif
         spilled |= fits ? 0u : 1u;
         lh[b] = fits ? (unsigned)r : SK_NOFIT;
@@ -462,9 +503,9 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         const unsigned* const myq = queue[st][wv];
         for (unsigned base = 0; base < total; base += 64) {
           const unsigned i = base + lane;
-          if (i < total) {
+          if (i < total && ((myq[i] >> 16) >> SK_LH_LOG2) == round) {
             const unsigned it = myq[i];
-            const unsigned at = atomicAdd(&lh[it >> 16], 1u);  // base + rank
+            const unsigned at = atomicAdd(&lh[(it >> 16) & (SK_LH - 1)], 1u);  // base + rank
             const u64* const wp = &pk_x[st][wv][it & 63u];
             ulonglong2 rec = sk_make_record(wp[0], wp[1], (int)((it >> 6) & 31u), (int)((it >> 11) & 31u), k);
             asm volatile("" : "+v"(rec.x), "+v"(rec.y));  // (built while the LDS answers)
@@ -483,7 +524,9 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
           const ulonglong2 w = make_ulonglong2(pk_x[st][wv][lane], pk_x[st][wv][lane + 1]);
           const SkRuns runs = sk_analyse<W>(w.x, w.y, sk_valid32(bad_window(bad, p0), k), CANON);
           sk_walk(runs, w.x, w.y, nkmax, CANON, [&](int jstart, int nk, unsigned mm) {
-            const unsigned at = atomicAdd(&lh[sk_bucket(mm, p1_log2)], 1u);
+            const unsigned b = sk_bucket(mm, p1_log2);
+            if ((b >> SK_LH_LOG2) != round) return;
+            const unsigned at = atomicAdd(&lh[b & (SK_LH - 1)], 1u);
             if (at < SK_NOFIT) part[(size_t)at] = sk_make_record(w.x, w.y, jstart, nk, k);
           });
         }
@@ -491,9 +534,10 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
     STAMP_ADD(tE, t0);
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
+    for (unsigned i = threadIdx.x; i < lhn; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     STAMP_ADD(tF, t0);
+    }  // rounds of 2^13 buckets
   }
 #ifdef MK_STAMP
   if (threadIdx.x == 0 && blockIdx.x < 1024) { u64* d = skq_dbg + (size_t)blockIdx.x * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = tF; d[6] = ntile; }
@@ -558,7 +602,8 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
   // few, long-lived workgroups: each one flushes 2 x p1 global atomics at its end (fewer still for a sample)
   const size_t hist_grid = sample_log2 ? SK_HIST_GRID / 2 : SK_HIST_GRID;
   if (!reuse) {  // (reuse: the regions of the previous chunk stand as they are, cursors back at their starts)
-    hipLaunchKernelGGL((mk_sk_hist_k<W, CANON>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS), 0, c->stream,
+    hipLaunchKernelGGL((mk_sk_hist_k<W, CANON>), dim3((unsigned)(tiles < hist_grid ? tiles : hist_grid)), dim3(SK_HIST_THREADS),
+                       2 * sizeof(unsigned) << p1_log2, c->stream,
                        (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
                        sample_log2);
     mk_launch_sk_scan(c, (const u64*)hist, (const u64*)khist, start, cursor, kstart, p1_log2, sample_log2, nkmax, surv_div, part_cap,
@@ -653,8 +698,14 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int k = c->k;
   // ~1.2K records (~10K windows) per bucket, between 256 and SK_MAX_P1 buckets
+  // MK_CORES=1 (experiment, round 4): half-sized buckets -- up to 2^14 of them -- counted by 512-thread workgroups with
+  // 4096-slot tables (mk_skcount_small.hip: 68-76 KB of LDS, so that two of them, or one and a scatter workgroup of the
+  // other context, share a CU)
+  static const bool cores = getenv("MK_CORES") != nullptr;
+  const int max_log2 = cores ? SK_MAX_P1_LOG2 : SK_LH_LOG2;
+  const size_t bucket_syms = cores ? SK_BUCKET_SYMS / 2 : SK_BUCKET_SYMS;
   int p1_log2 = 8;
-  while (p1_log2 < SK_MAX_P1_LOG2 && (seq_len >> p1_log2) > SK_BUCKET_SYMS) ++p1_log2;
+  while (p1_log2 < max_log2 && (seq_len >> p1_log2) > bucket_syms) ++p1_log2;
   if (const char* e = getenv("MK_P1_LOG2")) { int v = atoi(e); if (v >= 4 && v <= SK_MAX_P1_LOG2) p1_log2 = v; }
   c->p1_log2 = p1_log2;
   const size_t p1 = (size_t)1 << p1_log2;
@@ -719,7 +770,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
                        (unsigned)p1, atoi(e));
 #endif
   {
-    const int rc_count = mk_launch_sk_count(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact);
+    const int rc_count = cores ? mk_launch_sk_count_small(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact)
+                               : mk_launch_sk_count(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact);
     if (rc_count) return rc_count;
   }
   MK_HIP(hipGetLastError());
