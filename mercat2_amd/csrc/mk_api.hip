@@ -550,7 +550,10 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
       // chunk is expected to add -- only the owner ever replaces its table (it sizes it for its sharers as well), a sharer
       // that finds it too small upserts into its own for this chunk; the sum at the end is the same.
       mk_ctx* t = table_of_ctx(c);
-      const size_t expect = 2 * (size_t)c->surv_hint + 4096;
+      // (what this chunk is expected to add: the last full chunk's survivors -- late in a sample most of them are keys
+      // the table already holds; the spill list takes what a bad guess leaves no room for)
+      static const bool roomy = getenv("MK_FUSE_ROOMY") != nullptr;  // (A/B: twice the survivors, as first built)
+      const size_t expect = (roomy ? 2 * (size_t)c->surv_hint : (size_t)c->surv_hint) + 4096;
       if (t != c) {
         std::shared_lock<std::shared_mutex> rd(t->table_mu);
         size_t rows_now;
