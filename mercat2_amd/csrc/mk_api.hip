@@ -508,6 +508,10 @@ int mk_grow_run(mk_ctx* c, size_t more_rows) {
   return MK_OK;  // dense bins are allocated once; by-reference rows have their own table
 }
 
+// mk_bin.hip
+bool mk_binned_takes(const mk_ctx* c);
+int mk_launch_count_binned(mk_ctx* c, size_t seq_len, uint64_t min_count);
+
 // --------------------------------------------------------------------------- the pipeline
 #define MK_RETRY_GENERAL 1  // (internal) the speculative lane met input it does not handle: take the general path
 
@@ -796,7 +800,10 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
   else if (partitioned) {
     // (the super-k-mer scatter keeps 32-bit record indices in LDS)
     const bool sk = c->use_superkmer && c->alphabet == MK_ALPHABET_NT2 && c->k >= c->sk_min_k && c->k <= 32 && seq_len < 0xFE000000ull;
-    rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count);
+    // (keys of 16..26 bits -- nucleotide 8 <= k <= 11, protein k = 4, 5 -- are counted by direct index: mk_bin.hip)
+    const bool binned = !sk && mk_binned_takes(c) && seq_len < 0xFFFFFF00ull;
+    rc = sk ? mk_launch_count_superkmer(c, seq_len, min_count)
+            : (binned ? mk_launch_count_binned(c, seq_len, min_count) : mk_launch_count_partitioned(c, seq_len, min_count));
   }
   else if (c->mode == MK_MODE_HASH64) rc = mk_launch_count_hash64(c, seq_len);
   else if (c->mode == MK_MODE_HASH128) rc = sk2 ? mk_launch_count_superkmer2(c, seq_len, min_count) : mk_launch_count_ref128(c, seq_len);

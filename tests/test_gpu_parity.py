@@ -676,6 +676,41 @@ def test_fused_upsert_paths_are_exact(monkeypatch, canonical):
         assert ctx.stats()["fused_chunks"] == len(small) - 2
 
 
+@pytest.mark.parametrize("alpha,k", [("nt", 8), ("nt", 9), ("nt", 10), ("nt", 11), ("aa", 4), ("aa", 5)])
+def test_short_keys_counted_by_direct_index(alpha, k, monkeypatch):
+    """Keys of 16..26 bits (nucleotide 8 <= k <= 11, protein k = 4, 5) take mk_bin.hip: bucket = the key's top bits, one LDS
+    add per window into the bucket's bins.  Reads, a homopolymer and a two-letter repeat (every window in one or two
+    buckets), characters outside the alphabet, several chunks with their own filters, canonical keys; against the C
+    oracle."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(31 + k)
+    if alpha == "nt":
+        body = native.synth_reads(40_000, 5, 30_000, 150, 6).tobytes()
+        odd = b">poly\n" + b"A" * 70_000 + b"\n>rep\n" + b"AC" * 30_000 + b"\n>n\n" + b"ACGTNNACGTRYACGT" * 500 + b"\n"
+        a = native.ALPHABET_NT2
+    else:
+        letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+        body = b"".join(b">p%d\n" % i + letters[rng.integers(0, 20, int(rng.integers(5, 400)))].tobytes() + b"*\n" for i in range(6000))
+        odd = b">poly\n" + b"L" * 50_000 + b"\n>x\n" + b"MKVLAXXBZJOUACDEF" * 300 + b"\n"
+        a = native.ALPHABET_AA5
+    data = body + odd + body[: len(body) // 3]
+    offs = chunk_offsets(data, 900_000 if alpha == "nt" else 400_000)
+    assert len(offs) > 3
+    for c, canonical in ((1, False), (3, False), (2, True)):
+        if canonical and alpha != "nt":
+            continue
+        parts = [c_oracle.count_dict(data[x:y], k, 0 if canonical else c) for x, y in zip(offs[:-1], offs[1:])]
+        if canonical:
+            parts = [_fold_filter(p, c) for p in parts]
+        want = cpu_ref.merge_counts(parts)
+        with native.Counter(k, a, canonical=canonical) as ctx:
+            for x, y in zip(offs[:-1], offs[1:]):
+                ctx.count_chunk(memoryview(data)[x:y], c)
+            assert ctx.to_dict() == want, (alpha, k, c, canonical)
+            assert ctx.stats()["mode_name"] == "hash64"
+    del monkeypatch
+
+
 def test_long_lines_and_long_headers():
     """A 3 Mbp record on ONE line, a 200 kB header, and 70 kB of text in front of the first header:
     lines far longer than a parser wave (4 KiB) or workgroup."""
