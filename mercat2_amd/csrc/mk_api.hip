@@ -196,6 +196,12 @@ extern "C" int mk_create(int device, int alphabet, int k, mk_ctx** out) {
   c->use_speculation = getenv("MK_NO_SPECULATION") ? 0 : 1;
   c->use_reuse = getenv("MK_NO_REUSE") ? 0 : 1;
   c->use_fused = getenv("MK_NO_FUSE") ? 0 : 1;
+  // What a new context assumes about its first chunk (later chunks go by the chunk before): two windows per distinct key,
+  // five per record.  The count kernels plan their sub-range passes from it; a bucket that does not fit is split anyway.
+  // (1 and 8 -- every window a new key, full records -- made the first chunk of a read set take eight passes per bucket,
+  // 1.35 ms instead of 0.3.)
+  c->dup_hint = 2.0;
+  c->nk_hint = 5.0;
   if ((e = hipHostMalloc((void**)&c->h_info, 2 * sizeof(MkChunkInfo) + 8 * sizeof(u64), hipHostMallocDefault)) != hipSuccess)
     return fail(MK_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
   c->h_clean = (u64*)(c->h_info + 2);
@@ -638,8 +644,11 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     h->new_rows = 0;
     c->st.fused_chunks += 1;
     c->st.fuse_spilled += h->spilled;
-    // (what is launched below adds to the device's copy again, and that copy is read back later: start it from zero)
-    MK_HIP(hipMemsetAsync(&((MkChunkInfo*)c->info.p)->new_rows, 0, sizeof(unsigned long long), c->stream));
+    // (what is launched below adds to the device's copy again, and that copy is read back later: start it from zero.
+    // Nearly always nothing is: no spill, no rows kept as text -- then neither this fill nor that read-back is issued:
+    // two of the five tiny device operations a chunk cost besides its kernels)
+    if (h->spilled || h->survivors_ref)
+      MK_HIP(hipMemsetAsync(&((MkChunkInfo*)c->info.p)->new_rows, 0, sizeof(unsigned long long), c->stream));
     if (h->spilled) {  // the table was filling up: what the kernel set aside goes in now, into a table with room
       if ((rc = grow_run64(c, c->run_rows + (size_t)h->spilled)) != MK_OK) return rc;
       if ((rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)h->spilled)) != MK_OK) return rc;
@@ -662,9 +671,11 @@ static int process_chunk_fast(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min
     if (rc) return rc;
   }
   if ((rc = mk_launch_accumulate(c, min_count)) != MK_OK) return rc;  // (survivors of the by-reference chunk table, if any)
-  // the merge's row totals: copied back, not waited for
-  MK_HIP(hipMemcpyAsync(c->h_info + 1, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
-  c->pending_rows = true;
+  // the merge's row totals: copied back, not waited for (a fused launch that set nothing aside has reported them already)
+  if (!fused_done || h->spilled || h->survivors_ref) {
+    MK_HIP(hipMemcpyAsync(c->h_info + 1, c->info.p, sizeof(MkChunkInfo), hipMemcpyDeviceToHost, c->stream));
+    c->pending_rows = true;
+  }
   if (h->side && h->side >= min_count) c->run_side += h->side;
   // (hints for the next chunk come from FULL chunks: a sample's short last chunk -- a third of the coverage, half the
   // windows per distinct key, a fraction of the survivors -- made the first chunk of the next sample plan two sub-range
