@@ -168,6 +168,7 @@ struct mk_ctx {
   bool part_dirty = false;    // a partition was launched and its chunk has not been seen to end well (cursors may be anywhere)
   size_t part_prev_len = 0;
   int part_prev_p1 = 0;
+  int part_nseg = 1;            // regions per bucket of the last one-word partition (1, or 8: one per XCD)
   unsigned long long part_prev_minc = 0;
   int part_cooldown = 0;      // chunks that size their buckets afresh after a chunk overflowed inherited regions
   int use_reuse = 1;
@@ -247,13 +248,14 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
 bool mk_part_inherit(mk_ctx* c, size_t seq_len, int p1_log2, uint64_t min_count, bool sampled, bool exact);  // mk_skmer.hip
 void mk_launch_sk_scan(mk_ctx* c, const unsigned long long* hist, const unsigned long long* khist, unsigned long long* start,
                        unsigned* cursor, unsigned long long* kstart, int p1_log2, int sample_log2, int nkmax,
-                       unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas);
+                       unsigned long long surv_div, unsigned long long part_cap, unsigned long long surv_cap, float sigmas,
+                       int nseg);  // nseg: regions per bucket (1, or 8: one per XCD, mk_skmer.hip)
 // mk_skcount.hip: the count kernel of the one-word super-k-mer path over the bucket regions the scatter filled
 int mk_launch_sk_count(mk_ctx* c, const unsigned long long* start, unsigned* cursor, const unsigned long long* kstart,
-                       unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact);
+                       unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact, int nseg);
 // mk_skcount_small.hip: the same with 512-thread workgroups and 4096-slot tables (experiment MK_CORES)
 int mk_launch_sk_count_small(mk_ctx* c, const unsigned long long* start, unsigned* cursor, const unsigned long long* kstart,
-                             unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact);
+                             unsigned long long* nsurv, uint64_t min_count, int nkmax, size_t p1, bool exact, int nseg);
 // nt 33 <= k <= 64, two-word keys: mk_skmer2.hip; survivors {hi,lo,count} per bucket region
 int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bool exact = false);
 int mk_launch_import_ref128_regions(mk_ctx* c, const uint64_t* hi, const uint64_t* lo, const uint64_t* cnts,

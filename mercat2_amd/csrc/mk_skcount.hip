@@ -100,6 +100,17 @@ __device__ __forceinline__ ulonglong2 skc_ldrec(const ulonglong2* __restrict__ p
   return *p;
 #endif
 }
+// The next bucket's first records, asked for before the sweep of this one, are taken in (waited for) BEFORE the fused
+// upsert's claims go out after the sweep: the loop head then has no load to wait for -- a wait there is vmcnt(0), which
+// also waits for the claims just issued, a trip to the running table in HBM per bucket (7 % of the kernel by the stamps).
+#ifdef SKC_NO_TAKE_IN
+#define SKC_TAKE_IN(pre)
+#else
+#define SKC_TAKE_IN(pre)                                                                       \
+  do {                                                                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < SKC_PRE; ++h_) asm volatile("" ::"v"((pre)[h_].x), "v"((pre)[h_].y)); \
+  } while (0)
+#endif
 #define SKC_B 8          // k-mers of a record expanded and probed together
 #define SKC_WAVES (SKC_THREADS / 64)
 #ifndef SKC_PUSH
@@ -158,7 +169,7 @@ __device__ __forceinline__ void skf_spill(MkChunkInfo* info, u64* sp_keys, u64* 
   sp_cnts[at] = (u64)cnt;
 }
 // `old` = what the compare-and-swap at `slot` returned; probes on (with waits) until the key has a slot
-__device__ __forceinline__ void skf_finish(MkSlot* __restrict__ run, u64 mask, u64 key, unsigned cnt, u64 slot, u64 old, u64& fresh,
+__device__ __forceinline__ void skf_finish(MkSlot* __restrict__ run, u64 mask, u64 key, unsigned cnt, u64 slot, u64 old, unsigned& fresh,
                                            MkChunkInfo* info, u64* sp_keys, u64* sp_cnts, unsigned max_probe) {
   for (unsigned probe = 0;; ++probe) {
     if (old == MK_EMPTY || old == key) {
@@ -170,6 +181,45 @@ __device__ __forceinline__ void skf_finish(MkSlot* __restrict__ run, u64 mask, u
     slot = (slot + 1) & mask;
     old = atomicCAS(&run[slot].key, MK_EMPTY, key);
   }
+}
+
+// A bucket's records lie in nseg regions (1, or 9: one per XCD and a shared one, see mk_sk_scatterq_k / mk_sk_scan_k) --
+// region x of bucket b is [start[x * p1 + b], cursor[x * p1 + b]) -- and the kernel numbers them through, region after
+// region.  The table of a bucket: words 0..8 the number of records before region x, word 9 their total, words 10..18 region
+// x's first record minus the records before it (so that record j of the bucket is part[tab[10 + x] + j], x = the regions
+// with tab[x] <= j, less one).  Lanes 0..15 of the workgroup's last wave build the table of the NEXT bucket while the
+// current one is counted: they ask for its bounds at the top of the bucket and write the table just before barrier A, by
+// when the answers have long arrived; nothing else in the kernel waits for a bucket's bounds.
+#define SKC_SEG_WORDS 20
+#define SKC_SEG_MAX 9
+__device__ __forceinline__ unsigned skc_seg_at(const unsigned* tab, unsigned j, int nseg) {
+  if (nseg == 1) return tab[10] + j;
+  const uint4 a = *reinterpret_cast<const uint4*>(tab), b = *reinterpret_cast<const uint4*>(tab + 4);
+  const unsigned c = tab[8];
+  // (compare + add-with-carry, two instructions per region; the compiler made a compare, a select, a shift and an add of it)
+  unsigned x = 0;
+#define SKC_SEG_STEP(P) asm("v_cmp_le_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(x) : "v"(P), "v"(j) : "vcc")
+  SKC_SEG_STEP(a.y); SKC_SEG_STEP(a.z); SKC_SEG_STEP(a.w); SKC_SEG_STEP(b.x); SKC_SEG_STEP(b.y); SKC_SEG_STEP(b.z); SKC_SEG_STEP(b.w);
+  SKC_SEG_STEP(c);
+#undef SKC_SEG_STEP
+  return tab[10 + x] + j;
+}
+// (lanes 0..15 of one wave, all sixteen active; seg_lo / seg_hi: the bounds of region x, or of region 0 for x >= nseg)
+// A cursor past its region's end (runs that did not fit and went to the shared region, mk_sk_scatterq_k) counts to the end.
+__device__ __forceinline__ void skc_seg_publish(unsigned* tab, unsigned seg_lo, unsigned seg_hi, unsigned seg_end, int nseg) {
+  asm volatile("" : "+v"(seg_lo), "+v"(seg_hi), "+v"(seg_end));  // (nothing computed from the bounds before this point: they are waited for HERE)
+  const unsigned x = threadIdx.x & 15u, cnt = x < (unsigned)nseg ? (seg_hi < seg_end ? seg_hi : seg_end) - seg_lo : 0u;
+  unsigned inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const unsigned up = __shfl_up(inc, d, 16);
+    if (x >= (unsigned)d) inc += up;
+  }
+  if (x < SKC_SEG_MAX) {
+    tab[x] = inc - cnt;
+    tab[10 + x] = seg_lo - (inc - cnt);
+  }
+  if (x == 15) tab[9] = inc;
 }
 
 // Persistent: gridDim.x workgroups (one per CU) walk the buckets b = blockIdx.x, +gridDim.x, ...
@@ -185,7 +235,8 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
                                                              MkChunkInfo* __restrict__ info, u64 min_count,
                                                              u64* __restrict__ out_keys, u64* __restrict__ out_cnts,
                                                              int k, unsigned p1, double dup_hint, double nk_hint, u64* __restrict__ dbg,
-                                                             int dflags, MkSlot* __restrict__ run, u64 run_mask, unsigned max_probe) {
+                                                             int dflags, MkSlot* __restrict__ run, u64 run_mask, unsigned max_probe,
+                                                             int nseg) {
   constexpr bool FUSED = FCAP > 0;
   // (the longer list takes its LDS from the deferred-key stacks: two slots pushed at a time instead of four, measured 1 % slower)
   constexpr int PUSH = FCAP > SKC_FCAP_A ? 2 : SKC_PUSH;
@@ -205,6 +256,8 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   // per-pass flags, double-buffered by pass parity so that resetting them needs no extra barrier
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
+  __shared__ unsigned long long s_tot_distinct, s_tot_survivors;  // (kept by thread 0: chunk totals cost no registers)
+  __shared__ __attribute__((aligned(16))) unsigned s_seg[2][SKC_SEG_WORDS];  // the region tables of this bucket and the next
   __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
   // (fused: this launch is speculative -- the host looks at the parser's verdict only after it -- and what it merges into
   // the running table cannot be taken back: a chunk the host will refuse or parse again must not get that far)
@@ -213,53 +266,76 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
   if (s_abort) return;  // the scatter did not fit its (sampled) regions: the chunk is partitioned again
   for (unsigned i = threadIdx.x; i < SKC_SLOTS; i += blockDim.x) { tkey[i] = MK_EMPTY; tcnt[i] = 0; }
   if (threadIdx.x < 2) { s_distinct[threadIdx.x] = 0; s_overflow[threadIdx.x] = 0; s_emit[threadIdx.x] = 0; s_npend[threadIdx.x] = 0; }
-  if (threadIdx.x == 0) { s_windows = 0; s_fresh = 0; }
+  if (threadIdx.x == 0) { s_windows = 0; s_fresh = 0; s_tot_distinct = 0; s_tot_survivors = 0; }
   __syncthreads();
   // fused upsert: list f_cur holds the f_n entries whose compare-and-swaps are in flight (entry i: thread i, answer in f_old)
   unsigned f_cur = 0, f_n = 0;
-  u64 f_old = 0, fresh = 0;
+  u64 f_old = 0;
+  unsigned fresh = 0;  // (per lane; a chunk has fewer than 2^32 windows)
   const unsigned run_mask32 = (unsigned)run_mask;
   unsigned par = 0;
   const int kshift = 64 - 2 * k;
   const int lane = threadIdx.x & 63;
   u64* const myq = wq[threadIdx.x >> 6];
-  u64 distinct_total = 0, side = 0, survivors_total = 0, nerr = 0;
-  u64 windows = 0, records_total = 0;  // what the chunk held (every record is expanded at least once)
+  u64 side = 0, nerr = 0;
+  unsigned windows = 0;    // (per lane)
+  u64 records_total = 0;   // what the chunk held (every record is expanded at least once)
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, npass = 0;
   STAMP(t0);
 
   // prefetched state of the bucket about to be processed
   unsigned bn = blockIdx.x;
-  u64 lo_n = 0, hi_n = 0, ks_n = 0, ke_n = 0;  // records [lo_n, hi_n), survivor region [ks_n, ke_n)
+  u64 ks_n = 0, ke_n = 0;  // survivor region [ks_n, ke_n)
+  unsigned n_n = 0;        // its records
+  unsigned bp = 0;         // s_seg[bp]: the table of the current bucket
+  const bool seg_lane = threadIdx.x >= SKC_THREADS - 64 && threadIdx.x < SKC_THREADS - 48;  // the sixteen lanes that build the tables
+  // (index of this lane's region in start / cursor: recomputed at every use -- the empty asm keeps the compiler from
+  // hoisting 64-bit addresses out of the bucket loop into registers the kernel does not have)
+  auto seg_index = [&](unsigned bucket) {
+    unsigned x = threadIdx.x & 15u;
+    asm volatile("" : "+v"(x));
+    return (x < (unsigned)nseg ? x * p1 : 0u) + bucket;
+  };
+  unsigned seg_lo = 0, seg_hi = 0, seg_end = 0;  // (seg_lane) this lane's region of bucket bn -- first record, cursor, end -- on their way
   ulonglong2 pre[SKC_PRE];
 #pragma unroll
   for (int h = 0; h < SKC_PRE; ++h) pre[h] = make_ulonglong2(0, 0);
   if (bn < p1) {
-    lo_n = start[bn];
-    hi_n = cursor[bn];
     ks_n = kstart[bn];
     ke_n = kstart[bn + 1];
-#pragma unroll
-    for (int h = 0; h < SKC_PRE; ++h) {
-      const u64 j = SKC_JMAP(h);
-      if (j < hi_n - lo_n) pre[h] = skc_ldrec(part + lo_n + j);
+    if (seg_lane) {
+      seg_lo = (unsigned)start[seg_index(bn)];
+      seg_end = (unsigned)start[seg_index(bn) + 1];
+      seg_hi = cursor[seg_index(bn)];
+      skc_seg_publish(s_seg[0], seg_lo, seg_hi, seg_end, nseg);
     }
   }
+  __syncthreads();
+  if (bn < p1) {
+    n_n = s_seg[0][9];
+#pragma unroll
+    for (int h = 0; h < SKC_PRE; ++h) {
+      const unsigned j = (unsigned)SKC_JMAP(h);
+      if (j < n_n) pre[h] = skc_ldrec(part + skc_seg_at(s_seg[0], j, nseg));
+    }
+    SKC_TAKE_IN(pre);
+  }
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
-    const u64 lo = lo_n, n = hi_n - lo_n;  // records of this bucket
+    const u64 n = n_n;  // records of this bucket
+    const unsigned* const seg = s_seg[bp];
     u64* __restrict__ my_keys = out_keys + ks_n;
     u64* __restrict__ my_cnts = out_cnts + ks_n;
     const u64 region = ke_n - ks_n;
-    ulonglong2 first[SKC_PRE];
-#pragma unroll
-    for (int h = 0; h < SKC_PRE; ++h) first[h] = pre[h];
     // bounds of the next bucket: in flight while this one is counted
     bn = b + gridDim.x;
     if (bn < p1) {
-      lo_n = start[bn];
-      hi_n = cursor[bn];
       ks_n = kstart[bn];
       ke_n = kstart[bn + 1];
+      if (seg_lane) {  // (asked for here, looked at before barrier A)
+        seg_lo = (unsigned)start[seg_index(bn)];
+        seg_end = (unsigned)start[seg_index(bn) + 1];
+        seg_hi = cursor[seg_index(bn)];  // (lanes past nseg read region 0's bounds and count nothing: no select here, which would wait for seg_lo)
+      }
     }
     unsigned emitted = 0;
     if (n >> 27) {  // 2^27 records x 31 k-mers would overflow the 32-bit LDS counters
@@ -279,10 +355,10 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
       int s = s0;
       unsigned idx = 0;
       records_total += n;
-      u64 side_pass = 0, win_pass = 0;
+      u64 side_pass = 0;
+      unsigned win_pass = 0;
       bool side_done = false;
       bool first_pass = true;
-      const ulonglong2* __restrict__ src = part + lo;
       for (;;) {
         const unsigned sel_shift = SKC_SUB_BITS - s;
         side_pass = 0;  // the all-ones key (32 x 'T') is counted aside, once per bucket
@@ -294,13 +370,14 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           ulonglong2 recs2[SKC_PRE];
           if (first_pass && rb2 == 0) {
 #pragma unroll
-            for (int h = 0; h < SKC_PRE; ++h) recs2[h] = first[h];
+            for (int h = 0; h < SKC_PRE; ++h) recs2[h] = pre[h];  // (asked for during the bucket before)
           } else {
 #pragma unroll
             for (int h = 0; h < SKC_PRE; ++h) {
               const u64 j = rb2 + SKC_JMAP(h);
-              recs2[h] = j < n ? skc_ldrec(src + j) : make_ulonglong2(0, 0);
+              recs2[h] = j < n ? skc_ldrec(part + skc_seg_at(seg, (unsigned)j, nseg)) : make_ulonglong2(0, 0);
             }
+            SKC_TAKE_IN(recs2);  // (waited for on this path, so that the join with the path above has nothing to wait for)
           }
           STAMP_ADD(tF, t0);
 #pragma unroll
@@ -310,7 +387,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             //      the others are deferred
             const ulonglong2 rec = recs2[h];
             const int nk = (int)(rec.y & 63);
-            win_pass += side_done ? 0 : (u64)nk;
+            win_pass += side_done ? 0u : (unsigned)nk;
             u64 x = rec.x, y = rec.y;
             // (the whole wave walks the loop together -- lanes without a record or with a short one just have
             // no live slots -- because the deferred-key stack below is the wave's: every lane takes part)
@@ -463,16 +540,20 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #endif
           }
           STAMP_ADD(tC, t0);
-          if (*(volatile unsigned*)ovf) over = true;  // hint only; decided after the barrier below
+          // hint only; decided after the barrier below (an LDS read: a volatile access through the generic pointer was a
+          // flat load at system scope with a vmcnt(0) wait behind it)
+          if (__hip_atomic_load(&s_overflow[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) over = true;
         }
         STAMP_ADD(tA, t0);
         if (qcount) skc_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
+        if (first_pass && seg_lane && bn < p1) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);  // the next bucket's table
         first_pass = false;
         STAMP_ADD(tB, t0);
         __syncthreads();  // A: every insert of the pass is in the table
-        // (every wave has long read this bucket's bounds: put its cursor back to the region's start, so that the next
+        // (every wave has long read this bucket's bounds: put its cursors back to the regions' starts, so that the next
         // chunk can inherit the regions without a histogram and a scan -- see the launcher)
-        if (threadIdx.x == 0) cursor[b] = lo;
+        if (threadIdx.x < (unsigned)nseg) cursor[seg_index(b)] = seg[10 + threadIdx.x] + seg[threadIdx.x];
+        if (bn < p1) n_n = __builtin_amdgcn_readfirstlane(s_seg[bp ^ 1][9]);
         STAMP_ADD(tF, t0);
         ++npass;
         over = s_overflow[par] != 0;
@@ -511,8 +592,8 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         if (last && bn < p1) {
 #pragma unroll
           for (int h = 0; h < SKC_PRE; ++h) {
-            const u64 j = SKC_JMAP(h);
-            pre[h] = (j < hi_n - lo_n) ? skc_ldrec(part + lo_n + j) : make_ulonglong2(0, 0);
+            const unsigned j = (unsigned)SKC_JMAP(h);
+            pre[h] = j < n_n ? skc_ldrec(part + skc_seg_at(s_seg[bp ^ 1], j, nseg)) : make_ulonglong2(0, 0);
           }
         }
         // ---- emit (when complete) into the bucket's own region, and clear.  The sweep reads the COUNTS only
@@ -583,7 +664,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
         }
         __syncthreads();  // B: table is clear, counters of this pass are final
         emitted += s_emit[par];
-        distinct_total += s_distinct[par];
+        if (threadIdx.x == 0) s_tot_distinct += s_distinct[par];
         par ^= 1;
         if (FUSED) {
           // the list just filled is complete: thread i claims entry i's slot and does NOT wait (the answer is looked at
@@ -592,6 +673,7 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           if (threadIdx.x == 0) s_npend[f_cur] = 0;
           f_cur ^= 1;
           f_n = filled < (unsigned)FCAP ? filled : (unsigned)FCAP;
+          SKC_TAKE_IN(pre);  // (every pass: a wait that depends on `last` would leave the loop head its own)
           if (threadIdx.x < f_n) f_old = atomicCAS(&run[pend_slot[f_cur][threadIdx.x]].key, MK_EMPTY, pend_key[f_cur][threadIdx.x]);
         }
         STAMP_ADD(tD, t0);
@@ -614,37 +696,45 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
       }
     }
     if (n == 0 || (n >> 27)) {
-      // nothing was prefetched for the next bucket by a "last pass": do it here
+      // no pass, so no table and nothing prefetched for the next bucket: do it here (the whole workgroup comes this way)
+      if (seg_lane && bn < p1) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);
+      __syncthreads();
+      if (n && threadIdx.x < (unsigned)nseg) cursor[seg_index(b)] = seg[10 + threadIdx.x] + seg[threadIdx.x];
       if (bn < p1) {
+        n_n = __builtin_amdgcn_readfirstlane(s_seg[bp ^ 1][9]);
 #pragma unroll
         for (int h = 0; h < SKC_PRE; ++h) {
-          const u64 j = SKC_JMAP(h);
-          pre[h] = (j < hi_n - lo_n) ? skc_ldrec(part + lo_n + j) : make_ulonglong2(0, 0);
+          const unsigned j = (unsigned)SKC_JMAP(h);
+          pre[h] = j < n_n ? skc_ldrec(part + skc_seg_at(s_seg[bp ^ 1], j, nseg)) : make_ulonglong2(0, 0);
         }
+        SKC_TAKE_IN(pre);
       }
     }
+    bp ^= 1;
     if (threadIdx.x == 0) nsurv[b] = emitted;
-    survivors_total += emitted;
+    if (threadIdx.x == 0) s_tot_survivors += emitted;
     STAMP_ADD(tE, t0);
   }
   if (FUSED) {  // what is still in flight: finished here, with waits
     if (threadIdx.x < f_n)
       skf_finish(run, run_mask, pend_key[f_cur][threadIdx.x], pend_cnt[f_cur][threadIdx.x], (u64)pend_slot[f_cur][threadIdx.x], f_old, fresh,
                  info, out_keys, out_cnts, max_probe);
-    for (int d = 32; d > 0; d >>= 1) fresh += __shfl_down(fresh, d);
-    if (lane == 0 && fresh) atomicAdd(&s_fresh, (unsigned long long)fresh);
+    u64 fr = fresh;
+    for (int d = 32; d > 0; d >>= 1) fr += __shfl_down(fr, d);
+    if (lane == 0 && fr) atomicAdd(&s_fresh, (unsigned long long)fr);
   }
   {  // one global add per workgroup (adds to one address are serialised by the L2: ~4 ns each)
-    for (int d = 32; d > 0; d >>= 1) windows += __shfl_down(windows, d);
-    if (lane == 0 && windows) atomicAdd(&s_windows, (unsigned long long)windows);
+    u64 w = windows;
+    for (int d = 32; d > 0; d >>= 1) w += __shfl_down(w, d);
+    if (lane == 0 && w) atomicAdd(&s_windows, (unsigned long long)w);
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     if (FUSED && s_fresh) atomicAdd(&info->new_rows, (u64)s_fresh);
     if (s_windows) atomicAdd(&info->windows, (u64)s_windows);
     if (records_total) atomicAdd(&info->records, records_total);
-    if (distinct_total) atomicAdd(&info->distinct, distinct_total);
-    if (survivors_total) atomicAdd(&info->survivors, survivors_total);
+    if (s_tot_distinct) atomicAdd(&info->distinct, (u64)s_tot_distinct);
+    if (s_tot_survivors) atomicAdd(&info->survivors, (u64)s_tot_survivors);
     if (nerr) atomicAdd(&info->errors, nerr);
 #ifdef MK_STAMP
     if (dbg) { u64* d = dbg + (size_t)blockIdx.x * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = tE; d[5] = tF; d[6] = npass; }
@@ -988,7 +1078,7 @@ u64* mk_dbg_ptr = nullptr;
 // The count kernel over the p1 bucket regions the scatter has filled (start / cursor: records, kstart: survivor regions,
 // nsurv: survivors per bucket, written here).  Called by mk_launch_count_superkmer (mk_skmer.hip).
 int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64* kstart, u64* nsurv, uint64_t min_count, int nkmax,
-                       size_t p1, bool exact) {
+                       size_t p1, bool exact, int nseg) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int k = c->k;
   mk_prof_begin(c, MK_K_COUNT);
@@ -1006,6 +1096,7 @@ int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64*
     static const bool force_pre = getenv("MK_FORCE_PREFILTER") != nullptr;
     const bool pre = !no_pre && !exact && min_count >= 2 && nkmax <= SKC_B && force_pre;  // (opt-in only: see mk_sk_countp_k)
     if (pre) c->fused_last = false;
+    if (pre && nseg != 1) { c->err = "mk_launch_sk_count: the pre-filter kernel reads one region per bucket"; return MK_ERR_ARG; }
 #define SKP_LAUNCH(CANON, K32)                                                                                          \
   hipLaunchKernelGGL((mk_sk_countp_k<CANON, K32>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
                      (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
@@ -1018,7 +1109,7 @@ int mk_launch_sk_count(mk_ctx* c, const u64* start, SkCursor* cursor, const u64*
   hipLaunchKernelGGL((mk_sk_count_k<CANON, K32, FCAP>), dim3(grid), dim3(SKC_THREADS), 0, c->stream, (const ulonglong2*)c->part.p, \
                      (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count,                        \
                      (u64*)c->surv_keys.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, dbgbuf, dflags, \
-                     (MkSlot*)tab->run.p, (u64)(tab->run_slots ? tab->run_slots - 1 : 0), max_probe)
+                     (MkSlot*)tab->run.p, (u64)(tab->run_slots ? tab->run_slots - 1 : 0), max_probe, nseg)
 #define SKC_LAUNCH2(CANON, K32)                                                                                         \
   do {                                                                                                                  \
     if (fcap > 512) SKC_LAUNCH(CANON, K32, SKC_FCAP_B);                                                                 \

@@ -136,10 +136,25 @@ __device__ __forceinline__ u64 sk_cap(u64 h, int sample_log2, u64 weight, float 
   const float dev = sigmas * __builtin_sqrtf((float)((u64)weight << sample_log2) * (float)est);
   return est + (u64)dev + 1 + (sigmas > 0 ? 16 * weight : 0);
 }
+// Room for one XCD's share of a bucket whose sample held h records (eight of these also make the bucket's shared region,
+// which is then never smaller than sk_cap's room for the whole bucket): an eighth of the estimate, plus `sigmas` deviations of
+// (a) the share's own spread around that eighth and (b) an eighth of the estimate's error -- variances weight * est / nseg
+// and weight * S * est / nseg^2 (S = 2^sample_log2) -- plus a small floor.  Tiles go to the XCDs in turn (workgroup i runs on
+// XCD i mod 8), so for shuffled reads a share is as good as a 1-in-8 sample of the bucket; a run that does not fit goes to
+// the bucket's shared region, and only one that does not fit there either sends the chunk to the exact partition.
+__device__ __forceinline__ u64 sk_seg_cap(u64 h, int sample_log2, u64 weight, float sigmas, int nseg) {
+  const float est = (float)(h << sample_log2);
+  const float var = (float)weight * est * (1.0f / (float)nseg + (float)(1u << sample_log2) / (float)(nseg * nseg));
+  return (u64)(est / (float)nseg) + (u64)(sigmas * __builtin_sqrtf(var)) + 1 + (sigmas > 0 ? 4 * weight : 0);
+}
 __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ hist, const u64* __restrict__ khist,
                                                      u64* __restrict__ start, SkCursor* __restrict__ cursor, u64* __restrict__ kstart,
                                                      MkChunkInfo* __restrict__ info, int p1_log2, int sample_log2, int nkmax,
-                                                     u64 div, u64 part_cap, u64 surv_cap, float sigmas) {
+                                                     u64 div, u64 part_cap, u64 surv_cap, float sigmas, int nseg) {
+  // nseg = 9 (sampled sizes only): every bucket gets NINE regions -- start[x * p1 + b], cursor[x * p1 + b], all regions
+  // x = 0 first: one per XCD (x = 0..7), each sized for an eighth of the bucket (sk_seg_cap), and a shared one (x = 8)
+  // as large as the eight together, for the runs that do not fit their XCD's region (a repeat or a homopolymer puts all of
+  // a bucket's records into one tile, so into one XCD's region)
   constexpr int PER = SK_MAX_P1 / 1024;  // buckets per thread (p1 <= SK_MAX_P1)
   __shared__ u64 wsum[16], wksum[16];
   const unsigned p1 = 1u << p1_log2;
@@ -153,7 +168,8 @@ __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ his
     const unsigned i = lo + q;
     const bool on = (unsigned)q < per && i < p1;
     const u64 hk = on ? hist[i] : 0ull;  // records | k-mers << 32 (see the histogram kernels' flush)
-    cap[q] = on ? sk_cap(hk & 0xFFFFFFFFull, sample_log2, SK_R / SK_NKMAX, sigmas) : 0;
+    cap[q] = !on ? 0 : (nseg > 1 ? sk_seg_cap(hk & 0xFFFFFFFFull, sample_log2, SK_R / SK_NKMAX, sigmas, 8)
+                                 : sk_cap(hk & 0xFFFFFFFFull, sample_log2, SK_R / SK_NKMAX, sigmas));
     kcap[q] = on ? (sk_cap(hk >> 32, sample_log2, SK_R, sigmas) + div - 1) / div : 0;
     acc += cap[q];
     kacc += kcap[q];
@@ -169,19 +185,27 @@ __global__ __launch_bounds__(1024) void mk_sk_scan_k(const u64* __restrict__ his
   __syncthreads();
   u64 run = inc - acc, krun = kinc - kacc;
   for (int w = 0; w < wv; ++w) { run += wsum[w]; krun += wksum[w]; }
+  __shared__ u64 s_total;
   if (threadIdx.x == 1023) {
     const u64 total = run + acc, ktotal = krun + kacc;
-    start[p1] = total;
+    s_total = total;
+    const u64 all = nseg > 1 ? 16 * total : total;  // (8 regions + a shared one of 8 times the size)
+    start[(size_t)nseg * p1] = all;
     kstart[p1] = ktotal;
-    if (total > part_cap) atomicOr(&info->part_overflow, 1ull);  // (only a sampled estimate can get here)
+    if (all > part_cap) atomicOr(&info->part_overflow, 1ull);  // (only a sampled estimate can get here)
     if (ktotal > surv_cap) atomicOr(&info->part_overflow, 2ull);
   }
+  __syncthreads();
+  const u64 total = s_total;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const unsigned i = lo + q;
     if ((unsigned)q < per && i < p1) {
-      start[i] = run;
-      cursor[i] = run;
+      for (int x = 0; x < nseg; ++x) {
+        const u64 at = x < 8 ? (u64)x * total + run : 8 * total + 8 * run;
+        start[(size_t)x * p1 + i] = at;
+        cursor[(size_t)x * p1 + i] = (SkCursor)at;
+      }
       kstart[i] = krun;
       run += cap[q];
       krun += kcap[q];
@@ -338,7 +362,24 @@ template <int W, bool CANON, int SKQ_SUBT, int SKQ_QCAP>
 __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                          MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                          SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
-                                                         int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap) {
+                                                         int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap, int nseg) {
+  // nseg = 8: a bucket has one region per XCD and this workgroup fills the regions of the XCD it runs on.  Records of one
+  // bucket then reach their lines from one L2 only: the 16-byte stores of a (tile, bucket) run are merged there with the
+  // runs of the XCD's other tiles into whole lines before they go to HBM.  With one region per bucket the eight L2s each
+  // hold some sectors of every open line and write them out piecemeal (WRITE_SIZE 1.9 x the records, and in
+  // tools/xcd_scatter_probe.hip the stores cost 90-140 us per 13 M records against 12 us with regions private to an XCD).
+  // The XCD is read from the hardware register, not derived from blockIdx: which region a run lands in is then right
+  // whatever the dispatcher does (the cursors are ordinary device-wide atomics either way); only the regions' sizes
+  // assume that the tiles go round the XCDs evenly.
+  SkCursor* const shared_cursor = cursor + ((size_t)8 << p1_log2);  // (nseg > 1: the buckets' shared regions, see mk_sk_scan_k)
+  const u64* const shared_start = start + ((size_t)8 << p1_log2);
+  if (nseg > 1) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const size_t seg = xcc & 7u;
+    cursor += seg << p1_log2;
+    start += seg << p1_log2;
+  }
   __shared__ unsigned lh[SK_LH];  // as above: counts, then base + rank -- of the 2^13 buckets of the current round
   // every thread's first word; its second is the next lane's first, and a wave keeps the second word of its last lane
   // itself (pass 1 runs between wave barriers only: a wave must not read what another wave writes)
@@ -474,7 +515,27 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
         unsigned v[8], at[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = lh[threadIdx.x + (h + i) * SKQ_THREADS];
-        spilled |= sk_reserve8<SKQ_THREADS>(v, rcursor + h * SKQ_THREADS, rstart + h * SKQ_THREADS, SK_NOFIT, at);
+        unsigned nofit = sk_reserve8<SKQ_THREADS>(v, rcursor + h * SKQ_THREADS, rstart + h * SKQ_THREADS, SK_NOFIT, at);
+        if (nseg > 1 && __any(nofit)) {  // runs that do not fit the XCD's region: once more, in the bucket's shared region
+          // The cursor of the XCD's region has moved past the region's end by now and the count kernel reads a region up
+          // to its end then: the records between the last run that did fit and the end are nobody's (every later run
+          // starts past the end) -- the one run that found them free fills them with empty records.
+          unsigned v2[8], at2[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v2[i] = at[i] >= SK_NOFIT ? v[i] : 0u;
+            const unsigned pad = at[i] >= SK_NOFIT ? at[i] & 0xFFFFFFu : 0u;
+            if (pad) {
+              const u64 end = rstart[threadIdx.x + (h + i) * SKQ_THREADS + 1];
+              for (unsigned q = 0; q < pad; ++q) part[end - pad + q] = make_ulonglong2(0, 0);
+            }
+          }
+          nofit = sk_reserve8<SKQ_THREADS>(v2, shared_cursor + (size_t)round * SK_LH + h * SKQ_THREADS,
+                                           shared_start + (size_t)round * SK_LH + h * SKQ_THREADS, SK_NOFIT, at2);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) at[i] = v2[i] ? at2[i] : at[i];
+        }
+        spilled |= nofit;
 #pragma unroll
         for (int i = 0; i < 8; ++i) lh[threadIdx.x + (h + i) * SKQ_THREADS] = at[i];
       }
@@ -483,11 +544,16 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     {  // (fewer buckets than the most -- small chunks: a plain loop, one bucket at a time)
       for (unsigned b = threadIdx.x; b < lhn; b += SKQ_THREADS) {
         const unsigned v = lh[b];
-        const u64 r = v ? (u64)atomicAdd(&rcursor[b], v) : 0ull;
+        u64 r = v ? (u64)atomicAdd(&rcursor[b], v) : 0ull;
 #ifdef SK_ABL_COARSE
         const bool fits = v == 0 || r + v <= rstart[b + 64 < p1 ? b + 64 : p1];
 #else
-        const bool fits = v == 0 || r + v <= rstart[b + 1];
+        bool fits = v == 0 || r + v <= rstart[b + 1];
+        if (!fits && nseg > 1) {  // (the bucket's shared region; what was free at the end of the XCD's: empty records, as above)
+          for (u64 q = r; q < rstart[b + 1]; ++q) part[q] = make_ulonglong2(0, 0);
+          r = (u64)atomicAdd(&shared_cursor[b], v);
+          fits = r + v <= shared_start[b + 1];
+        }
 #endif
         spilled |= fits ? 0u : 1u;
         lh[b] = fits ? (unsigned)r : SK_NOFIT;
@@ -583,16 +649,16 @@ __global__ __launch_bounds__(256) void mk_sk_expsort_k(ulonglong2* __restrict__ 
 
 #ifndef SK_TU_CANON
 void mk_launch_sk_scan(mk_ctx* c, const u64* hist, const u64* khist, u64* start, SkCursor* cursor, u64* kstart, int p1_log2,
-                       int sample_log2, int nkmax, u64 surv_div, u64 part_cap, u64 surv_cap, float sigmas) {
+                       int sample_log2, int nkmax, u64 surv_div, u64 part_cap, u64 surv_cap, float sigmas, int nseg) {
   hipLaunchKernelGGL(mk_sk_scan_k, dim3(1), dim3(1024), 0, c->stream, hist, khist, start, cursor, kstart,
-                     (MkChunkInfo*)c->info.p, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas);
+                     (MkChunkInfo*)c->info.p, p1_log2, sample_log2, nkmax, surv_div, part_cap, surv_cap, sigmas, nseg);
 }
 
 #endif
 
 template <int W, bool CANON>
 static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
-                     u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse) {
+                     u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse, int nseg) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   float sigmas = 6.0f;  // MK_SAMPLE_SIGMAS=0 makes the sampled sizes too small on purpose (tests of the exact second pass)
   if (const char* e = getenv("MK_SAMPLE_SIGMAS")) sigmas = (float)atof(e);
@@ -607,7 +673,7 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
                        (const u64*)c->codes.p, (const u64*)c->bad.p, info, hist, khist, p1_log2, c->k, nkmax, threads, c->canonical,
                        sample_log2);
     mk_launch_sk_scan(c, (const u64*)hist, (const u64*)khist, start, cursor, kstart, p1_log2, sample_log2, nkmax, surv_div, part_cap,
-                      surv_cap, sigmas);
+                      surv_cap, sigmas, nseg);
   }
   static const bool walked = getenv("MK_SCATTER_WALK") != nullptr;  // (the per-lane walks of the first version, for A/B runs)
   // three sub-tiles when the lanes of the chunk before listed few enough records for the shorter queues (mean + 3 sigma
@@ -625,10 +691,10 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
     const dim3 qgrid((unsigned)(qtiles < SK_SCAT_GRID ? qtiles : SK_SCAT_GRID));
     if (three)
       hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON, 3, 376>), qgrid, dim3(SKQ_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap, nseg);
     else
       hipLaunchKernelGGL((mk_sk_scatterq_k<W, CANON, 2, 512>), qgrid, dim3(SKQ_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap);
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (ulonglong2*)c->part.p, p1_log2, c->k, nkmax, qtiles, qcap, nseg);
   }
 #ifdef MK_STAMP
   if (!walked) {
@@ -649,10 +715,10 @@ static void launch_wc(mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sam
 // histogram + scan + scatter for W = k - 10 minimizer candidates per window; false: W out of range
 template <bool CANON>
 static bool sk_partition(int W, mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap, u64 surv_cap,
-                         u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse) {
+                         u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse, int nseg) {
   switch (W) {
 #define SK_CASE(W_)                                                                                                      \
-  case W_: launch_wc<W_, CANON>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, part_cap, surv_cap, hist, start, cursor, khist, kstart, reuse); return true;
+  case W_: launch_wc<W_, CANON>(c, seq_len, p1_log2, nkmax, sample_log2, surv_div, part_cap, surv_cap, hist, start, cursor, khist, kstart, reuse, nseg); return true;
     SK_CASE(2) SK_CASE(3) SK_CASE(4) SK_CASE(5) SK_CASE(6) SK_CASE(7)
     SK_CASE(8) SK_CASE(9) SK_CASE(10) SK_CASE(11) SK_CASE(12) SK_CASE(13) SK_CASE(14) SK_CASE(15) SK_CASE(16)
     SK_CASE(17) SK_CASE(18) SK_CASE(19) SK_CASE(20) SK_CASE(21) SK_CASE(22)
@@ -663,12 +729,12 @@ static bool sk_partition(int W, mk_ctx* c, size_t seq_len, int p1_log2, int nkma
 
 #ifdef SK_TU_CANON
 bool mk_sk_partition_canon(int W, mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap,
-                           u64 surv_cap, u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse) {
-  return sk_partition<true>(W, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, part_cap, surv_cap, hist, start, cursor, khist, kstart, reuse);
+                           u64 surv_cap, u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse, int nseg) {
+  return sk_partition<true>(W, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, part_cap, surv_cap, hist, start, cursor, khist, kstart, reuse, nseg);
 }
 #else
 bool mk_sk_partition_canon(int W, mk_ctx* c, size_t seq_len, int p1_log2, int nkmax, int sample_log2, u64 surv_div, u64 part_cap,
-                           u64 surv_cap, u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse);
+                           u64 surv_cap, u64* hist, u64* start, SkCursor* cursor, u64* khist, u64* kstart, bool reuse, int nseg);
 
 // Chunks of one sample are equally long (the Chunker cuts at the first record past the size) and drawn from the
 // same text: a chunk whose predecessor sized its buckets from the sampled histogram -- the estimate plus six
@@ -727,11 +793,22 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
     if (!exact && seq_len >= min_len) sample_log2 = want;
   }
   c->part_sampled = sample_log2 != 0;
+  // regions per bucket: one per XCD when the sizes come from a sample (the exact partition keeps one: a bucket's exact
+  // size says nothing exact about its eighths); MK_XSEG=0 keeps one everywhere (A/B runs, tests)
+  const bool xseg_on = !(getenv("MK_XSEG") && atoi(getenv("MK_XSEG")) == 0);
+  static const bool walked_env = getenv("MK_SCATTER_WALK") != nullptr;
+  static const bool force_pre = getenv("MK_FORCE_PREFILTER") != nullptr;  // (that count kernel reads one region per bucket)
+  const int nseg = (xseg_on && sample_log2 != 0 && !walked_env && !force_pre && p1_log2 <= SK_LH_LOG2 &&
+                    2 * (u64)seq_len + 64 < 0xFF000000ull) ? 9 : 1;  // (32-bit cursors over twice the room)
+  if (nseg != c->part_nseg) c->part_reuse_ok = false;  // (regions of the other layout cannot be inherited)
+  c->part_nseg = nseg;
   const bool reuse = mk_part_inherit(c, seq_len, p1_log2, min_count, sample_log2 != 0, exact);
   int rc;
-  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
-  // worst case one record per window
-  const size_t part_cap = seq_len + 64;
+  // hist p1 | start p1 + 1 | cursor (p1 words) | khist p1 | kstart p1 + 1 | (p1) | nsurv p1 | start of the 9 p1 regions + 1 | their cursors
+  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16 + 14 * p1 + 8) * sizeof(u64))) != MK_OK) return rc;
+  // worst case one record per window (nine regions per bucket: the shared ones alone have that much, the eight others as
+  // much again -- untouched memory for the most part)
+  const size_t part_cap = nseg > 1 ? 2 * seq_len + 64 : seq_len + 64;
   if ((rc = mk_buf_reserve(c, c->part, part_cap * sizeof(ulonglong2))) != MK_OK) return rc;
   // a bucket with m k-mers has at most ceil(m / min_count) survivors: that bounds its region
   // (regions sized from a sample carry its error margin: half as much room again plus the per-bucket floor)
@@ -751,15 +828,19 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   u64* khist = start + p1 + 1 + p1;
   u64* kstart = khist + p1;
   u64* nsurv = kstart + p1 + 1 + p1;  // (the p1 words in between: a cursor array the 8-byte-key path uses)
+  if (nseg > 1) {
+    start = hist + 7 * p1 + 16;
+    cursor = (SkCursor*)(start + 9 * p1 + 8);
+  }
   if (!reuse) MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   mk_prof_begin(c, MK_K_PART);
   // (the canonical instances live in a translation unit of their own, mk_skmer_canon.hip: half the compile time each)
   if (c->canonical) {
-    if (!mk_sk_partition_canon(k - SK_M + 1, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse)) {
+    if (!mk_sk_partition_canon(k - SK_M + 1, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse, nseg)) {
       c->err = "mk_launch_count_superkmer: k out of range";
       return MK_ERR_ARG;
     }
-  } else if (!sk_partition<false>(k - SK_M + 1, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse)) {
+  } else if (!sk_partition<false>(k - SK_M + 1, c, seq_len, p1_log2, nkmax, sample_log2, surv_div, (u64)part_cap, (u64)surv_cap, hist, start, cursor, khist, kstart, reuse, nseg)) {
     c->err = "mk_launch_count_superkmer: k out of range";
     return MK_ERR_ARG;
   }
@@ -770,8 +851,8 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
                        (unsigned)p1, atoi(e));
 #endif
   {
-    const int rc_count = cores ? mk_launch_sk_count_small(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact)
-                               : mk_launch_sk_count(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact);
+    const int rc_count = cores ? mk_launch_sk_count_small(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact, nseg)
+                               : mk_launch_sk_count(c, (const u64*)start, cursor, (const u64*)kstart, nsurv, min_count, nkmax, p1, exact, nseg);
     if (rc_count) return rc_count;
   }
   MK_HIP(hipGetLastError());

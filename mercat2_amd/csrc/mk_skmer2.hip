@@ -1042,7 +1042,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
                        (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
   if (!reuse)
     mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
-                      (u64)surv_cap, sigmas);
+                      (u64)surv_cap, sigmas, 1);
   if (c->canonical)
     hipLaunchKernelGGL(mk_sk2_scatter_k<true>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);

@@ -50,8 +50,8 @@ typedef unsigned SkCursor;
 // masked off) and the 8 region ends are in flight together, one wait.  Written out: under the scatter kernels' register
 // pressure the compiler spilled the 8 addresses and put a full wait in front of every atomic and every load (in-kernel
 // stamps, mk_sk_scatterq_k: 34 K of a tile's 104 K cycles went into this block).  Base pointers are uniform (scalar
-// registers), one 32-bit offset per thread.  base[i] = the run's first record, or `nofit`; returns 1 when a run does
-// not fit.
+// registers), one 32-bit offset per thread.  base[i] = the run's first record, or `nofit` (0xFF000000) + the free records
+// the run found at the region's end (fewer than its own, so below 2^24); returns 1 when a run does not fit.
 // (s_nop 4 in front of every access: the base pointers may have just come out of a v_readlane -- the compiler parks scalar
 // registers in vector lanes here -- and a vector-memory instruction must not read a scalar register within 5 cycles of a
 // vector instruction writing it; inside inline assembly the compiler does not insert those wait states itself.)
@@ -89,7 +89,9 @@ __device__ __forceinline__ unsigned sk_reserve8(const unsigned (&count)[8], SkCu
   for (int i = 0; i < 8; ++i) {
     const bool fits = count[i] == 0 || (u64)r[i] + count[i] <= lim[i];
     spilled |= fits ? 0u : 1u;
-    base[i] = fits ? r[i] : nofit;
+    // (a run that does not fit: `nofit` plus, in its low 24 bits, the records still free at the region's end when it came --
+    // nothing else will ever be stored there, every later run of the bucket starts past the end: see the callers)
+    base[i] = fits ? r[i] : nofit | ((u64)r[i] < lim[i] ? (unsigned)(lim[i] - r[i]) : 0u);
   }
   return spilled;
 }

@@ -913,13 +913,16 @@ def test_many_contexts_and_threads():
                 assert ctx.to_dict() == want
 
 
-@pytest.mark.parametrize("sigmas,expect_retry", [("6", False), ("0", True)])
-def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_retry):
+@pytest.mark.parametrize("sigmas,xseg,expect_retry", [("6", "1", False), ("6", "0", False), ("0", "0", True), ("0", "1", None)])
+def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, xseg, expect_retry):
     """Big chunks size their super-k-mer buckets from a 1-in-8 sample of the histogram; a chunk whose
     sample was too small anywhere is partitioned again exactly.  Same tables either way (forced here on
-    a small input: MK_SAMPLE_MIN=0; MK_SAMPLE_SIGMAS=0 removes the safety margin so the second pass runs)."""
+    a small input: MK_SAMPLE_MIN=0; MK_SAMPLE_SIGMAS=0 removes the safety margin so the second pass runs).
+    With a region per XCD and bucket (the default, MK_XSEG=1) runs that do not fit their region go to the bucket's
+    shared region first: without a margin most of the records travel that way, and the exact pass is not needed."""
     monkeypatch.setenv("MK_SAMPLE_MIN", "0")
     monkeypatch.setenv("MK_SAMPLE_SIGMAS", sigmas)
+    monkeypatch.setenv("MK_XSEG", xseg)
     data = native.synth_reads(200_000, 41, 60_000, 150, 42).tobytes()
     low = b">poly\n" + b"A" * 30_000 + b"\n>rep\n" + b"ACGTTGCAAG" * 4_000 + b"\n"
     from oracle import c_oracle
@@ -933,7 +936,40 @@ def test_sampled_bucket_sizes_and_exact_second_pass(monkeypatch, sigmas, expect_
                 got = ctx.to_dict()
                 retries = ctx.stats()["part_retries"]
             assert got == want, (k, c, sigmas)
-            assert (retries > 0) == expect_retry, (k, c, sigmas, retries)
+            if expect_retry is not None:
+                assert (retries > 0) == expect_retry, (k, c, sigmas, retries)
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_bucket_regions_per_xcd_give_the_same_tables(monkeypatch, canonical):
+    """Sampled bucket sizes come with one region per XCD and bucket (mk_sk_scatterq_k: a workgroup fills the regions of the
+    XCD it runs on; the count kernel reads a bucket's eight regions one after the other); MK_XSEG=0 keeps one region per
+    bucket.  Same tables, no exact second pass for reads, and chunks that inherit their regions from the chunk before
+    still do so when the layout changes in between (they size their own then)."""
+    monkeypatch.setenv("MK_SAMPLE_MIN", "0")
+    from oracle import c_oracle
+    data = native.synth_reads(300_000, 11, 80_000, 150, 12).tobytes()
+    tail = data[: len(data) // 3]
+    for k, c in ((31, 2), (21, 1), (14, 3), (32, 1)):
+        parts = [c_oracle.count_dict(x, k, 0 if canonical else c) for x in (data, data, tail)]
+        want = cpu_ref.merge_counts([_fold_filter(p, c) for p in parts] if canonical else parts)
+        for xseg in ("1", "0"):
+            monkeypatch.setenv("MK_XSEG", xseg)
+            with native.Counter(k, native.ALPHABET_NT2, canonical=canonical) as ctx:
+                ctx.count_chunk(data, c)
+                ctx.count_chunk(data, c)   # inherits the regions of the first
+                ctx.count_chunk(tail, c)
+                got = ctx.to_dict()
+                st = ctx.stats()
+            assert got == want, (k, c, xseg)
+            assert st["part_retries"] == 0 and st["part_reused"] == 1, (k, c, xseg, st["part_retries"], st["part_reused"])
+        # the layout changing between chunks of one context
+        with native.Counter(k, native.ALPHABET_NT2, canonical=canonical) as ctx:
+            for xseg, chunk in (("1", data), ("0", data), ("1", tail)):
+                monkeypatch.setenv("MK_XSEG", xseg)
+                ctx.count_chunk(chunk, c)
+            assert ctx.to_dict() == want, (k, c, "mixed")
+            assert ctx.stats()["part_reused"] == 0
 
 
 def test_equal_chunks_inherit_bucket_regions(monkeypatch):
