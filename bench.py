@@ -560,7 +560,7 @@ def main():
                 configs[name] = {"value": tot * steps / d2, "unit": "bases/s", "ms_per_step": d2 / steps * 1e3, "steps": steps, "warmup": warm,
                                  "rows": rows2, "chunks": nch, "k": kk, "reads": reads, "genome": genome, "canonical": canon,
                                  "mode": s2["mode_name"], "count_kernel_ms_per_launch": ms_l, "count_kernel_frac": ach / HBM_PEAK_GBS,
-                                 "bytes_per_window": bpw,
+                                 "bytes_per_window": bpw, "part_retries": s2["part_retries"], "part_reused": s2["part_reused"],
                                  "verified_rows": verify_rows(rows2, "weak", reads, genome, kk, 0, canon, gseed, rseed)}
                 vt = verify_table(e2, "weak", reads, genome, kk, 0, canon, gseed, rseed)
                 if vt is not None:
@@ -641,6 +641,8 @@ def main():
             "kernel_ms_per_step": {n: st["ms_" + n] / args.steps for n in ("parse", "pack", "part", "count", "exotic", "filter", "export")},
             # chunks whose count kernel merged its survivors into the running table itself (no import kernel), and what those set aside
             "fused_chunks_per_step": st["fused_chunks"] / args.steps, "fuse_spilled": st["fuse_spilled"],
+            # chunks partitioned a second time (sampled bucket regions too small) / chunks that inherited the regions of the chunk before
+            "part_retries": st["part_retries"], "part_reused": st["part_reused"],
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": launches, "ms_per_launch": ms_launch,

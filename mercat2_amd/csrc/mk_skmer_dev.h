@@ -223,6 +223,46 @@ __device__ __forceinline__ unsigned sk_cut_starts(unsigned starts, unsigned vali
   return s2;
 }
 
+// ---- regions of a bucket, as the count kernels see them (mk_skcount.hip, mk_skmer2.hip)
+// A bucket's records lie in nseg regions (1, or 9: one per XCD and a shared one, see mk_sk_scatterq_k / mk_sk_scan_k) --
+// region x of bucket b is [start[x * p1 + b], cursor[x * p1 + b]) -- and the kernel numbers them through, region after
+// region.  The table of a bucket: words 0..8 the number of records before region x, word 9 their total, words 10..18 region
+// x's first record minus the records before it (so that record j of the bucket is part[tab[10 + x] + j], x = the regions
+// with tab[x] <= j, less one).  Lanes 0..15 of the workgroup's last wave build the table of the NEXT bucket while the
+// current one is counted: they ask for its bounds at the top of the bucket and write the table just before barrier A, by
+// when the answers have long arrived; nothing else in the kernel waits for a bucket's bounds.
+#define SKC_SEG_WORDS 20
+#define SKC_SEG_MAX 9
+__device__ __forceinline__ unsigned skc_seg_at(const unsigned* tab, unsigned j, int nseg) {
+  if (nseg == 1) return tab[10] + j;
+  const uint4 a = *reinterpret_cast<const uint4*>(tab), b = *reinterpret_cast<const uint4*>(tab + 4);
+  const unsigned c = tab[8];
+  // (compare + add-with-carry, two instructions per region; the compiler made a compare, a select, a shift and an add of it)
+  unsigned x = 0;
+#define SKC_SEG_STEP(P) asm("v_cmp_le_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(x) : "v"(P), "v"(j) : "vcc")
+  SKC_SEG_STEP(a.y); SKC_SEG_STEP(a.z); SKC_SEG_STEP(a.w); SKC_SEG_STEP(b.x); SKC_SEG_STEP(b.y); SKC_SEG_STEP(b.z); SKC_SEG_STEP(b.w);
+  SKC_SEG_STEP(c);
+#undef SKC_SEG_STEP
+  return tab[10 + x] + j;
+}
+// (lanes 0..15 of one wave, all sixteen active; seg_lo / seg_hi: the bounds of region x, or of region 0 for x >= nseg)
+// A cursor past its region's end (runs that did not fit and went to the shared region, mk_sk_scatterq_k) counts to the end.
+__device__ __forceinline__ void skc_seg_publish(unsigned* tab, unsigned seg_lo, unsigned seg_hi, unsigned seg_end, int nseg) {
+  asm volatile("" : "+v"(seg_lo), "+v"(seg_hi), "+v"(seg_end));  // (nothing computed from the bounds before this point: they are waited for HERE)
+  const unsigned x = threadIdx.x & 15u, cnt = x < (unsigned)nseg ? (seg_hi < seg_end ? seg_hi : seg_end) - seg_lo : 0u;
+  unsigned inc = cnt;
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const unsigned up = __shfl_up(inc, d, 16);
+    if (x >= (unsigned)d) inc += up;
+  }
+  if (x < SKC_SEG_MAX) {
+    tab[x] = inc - cnt;
+    tab[10 + x] = seg_lo - (inc - cnt);
+  }
+  if (x == 15) tab[9] = inc;
+}
+
 // in-kernel phase stamps of -DMK_STAMP builds (wave 0 of a workgroup; s_memtime ticks)
 #ifdef MK_STAMP
 #define STAMP(var) { __builtin_amdgcn_sched_barrier(0); unsigned long long t__; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) :: "memory"); __builtin_amdgcn_sched_barrier(0); var = t__; }
