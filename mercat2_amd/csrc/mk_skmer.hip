@@ -363,11 +363,10 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
                                                          MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                          SkCursor* __restrict__ cursor, ulonglong2* __restrict__ part,
                                                          int p1_log2, int k, int nkmax, size_t ntiles, unsigned qcap, int nseg) {
-  // nseg = 8: a bucket has one region per XCD and this workgroup fills the regions of the XCD it runs on.  Records of one
-  // bucket then reach their lines from one L2 only: the 16-byte stores of a (tile, bucket) run are merged there with the
-  // runs of the XCD's other tiles into whole lines before they go to HBM.  With one region per bucket the eight L2s each
-  // hold some sectors of every open line and write them out piecemeal (WRITE_SIZE 1.9 x the records, and in
-  // tools/xcd_scatter_probe.hip the stores cost 90-140 us per 13 M records against 12 us with regions private to an XCD).
+  // nseg = 9: a bucket has one region per XCD (and a shared one, below) and this workgroup fills the regions of the XCD
+  // it runs on: the sectors of a line then reach the memory side from one L2 instead of eight (scatter -10..-17 %; the bytes
+  // written stay what they were, 32 per 16-byte record: a partly written sector leaves the L2 long before its neighbour
+  // record arrives -- DESIGN.md 4.2, tools/xcd_scatter_probe.hip).
   // The XCD is read from the hardware register, not derived from blockIdx: which region a run lands in is then right
   // whatever the dispatcher does (the cursors are ordinary device-wide atomics either way); only the regions' sizes
   // assume that the tiles go round the XCDs evenly.
