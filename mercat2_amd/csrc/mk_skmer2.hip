@@ -320,18 +320,7 @@ template <int SK2Q_SUBT, int SK2Q_QCAP>
 __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void mk_sk2_scatterq_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                       MkChunkInfo* __restrict__ info, const u64* __restrict__ start,
                                                                       SkCursor* __restrict__ cursor, Sk2Rec* __restrict__ part,
-                                                                      int p1_log2, int k, size_t ntiles, unsigned qcap, int nseg) {
-  // nseg = 9: a region per XCD and bucket plus a shared one per bucket, as in mk_sk_scatterq_k (mk_skmer.hip) -- this
-  // workgroup fills the regions of the XCD it runs on
-  SkCursor* const shared_cursor = cursor + ((size_t)8 << p1_log2);
-  const u64* const shared_start = start + ((size_t)8 << p1_log2);
-  if (nseg > 1) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const size_t seg = xcc & 7u;
-    cursor += seg << p1_log2;
-    start += seg << p1_log2;
-  }
+                                                                      int p1_log2, int k, size_t ntiles, unsigned qcap) {
   __shared__ unsigned lh[SK2_MAX_P1];  // counts, then base + rank (record indices stay below SK2_NOFIT: the launcher checks)
   // every thread's first word, wave by wave, and the three words after the wave's last lane: a thread's words 1..3 are
   // the first words of the three threads to its right (pass 1 runs between wave barriers only: a wave reads its own row)
@@ -419,25 +408,7 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         unsigned v[8], at[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = lh[threadIdx.x + (h + i) * SK2Q_THREADS];
-        unsigned nofit = sk_reserve8<SK2Q_THREADS>(v, cursor + h * SK2Q_THREADS, start + h * SK2Q_THREADS, SK2_NOFIT, at);
-        if (nseg > 1 && __any(nofit)) {  // once more in the bucket's shared region; the XCD's region is closed with empty records
-          unsigned v2[8], at2[8];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            v2[i] = at[i] >= SK2_NOFIT ? v[i] : 0u;
-            const unsigned pad = at[i] >= SK2_NOFIT ? at[i] & 0xFFFFFFu : 0u;
-            if (pad) {
-              const u64 end = start[threadIdx.x + (h + i) * SK2Q_THREADS + 1];
-              Sk2Rec none;
-              none.r0 = none.r1 = none.r2 = none.nk = 0;
-              for (unsigned q = 0; q < pad; ++q) part[end - pad + q] = none;
-            }
-          }
-          nofit = sk_reserve8<SK2Q_THREADS>(v2, shared_cursor + h * SK2Q_THREADS, shared_start + h * SK2Q_THREADS, SK2_NOFIT, at2);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) at[i] = v2[i] ? at2[i] : at[i];
-        }
-        spilled |= nofit;
+        spilled |= sk_reserve8<SK2Q_THREADS>(v, cursor + h * SK2Q_THREADS, start + h * SK2Q_THREADS, SK2_NOFIT, at);
 #pragma unroll
         for (int i = 0; i < 8; ++i) lh[threadIdx.x + (h + i) * SK2Q_THREADS] = at[i];
       }
@@ -446,15 +417,8 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     {  // (small chunks, fewer buckets: one at a time)
       for (unsigned b = threadIdx.x; b < p1; b += SK2Q_THREADS) {
         const unsigned v = lh[b];
-        u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
-        bool fits = v == 0 || r + v <= start[b + 1];
-        if (!fits && nseg > 1) {
-          Sk2Rec none;
-          none.r0 = none.r1 = none.r2 = none.nk = 0;
-          for (u64 q = r; q < start[b + 1]; ++q) part[q] = none;
-          r = (u64)atomicAdd(&shared_cursor[b], v);
-          fits = r + v <= shared_start[b + 1];
-        }
+        const u64 r = v ? (u64)atomicAdd(&cursor[b], v) : 0ull;
+        const bool fits = v == 0 || r + v <= start[b + 1];
         spilled |= fits ? 0u : 1u;
         lh[b] = fits ? (unsigned)r : SK2_NOFIT;
       }
@@ -565,14 +529,13 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
                                                                MkChunkInfo* __restrict__ info, u64 min_count,
                                                                u64* __restrict__ out_hi, u64* __restrict__ out_lo,
                                                                u64* __restrict__ out_cnt, int k, unsigned p1,
-                                                               double dup_hint, double nk_hint, int nseg) {
+                                                               double dup_hint, double nk_hint) {
   __shared__ __attribute__((aligned(16))) ulonglong2 tkey[SK2C_SLOTS];  // {hi, lo}
   __shared__ unsigned tcnt[SK2C_SLOTS];                                   // 0 free, LOCK being written, else the count
   __shared__ __attribute__((aligned(16))) ulonglong2 wq[SK2C_WAVES][SK2C_QCAP];  // deferred keys, one stack per wave
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
   __shared__ unsigned s_abort;  // (read once per workgroup: other workgroups of this launch may set the flag meanwhile)
-  __shared__ __attribute__((aligned(16))) unsigned s_seg[2][SKC_SEG_WORDS];  // the bucket's regions (mk_skmer_dev.h), by bucket parity
   if (threadIdx.x == 0) { s_abort = info->part_overflow != 0; s_windows = 0; }
   __syncthreads();
   if (s_abort) return;  // the scatter did not fit its (sampled) regions: the chunk is partitioned again
@@ -583,29 +546,8 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
   const int lane = threadIdx.x & 63;
   const u64 lomask = (k >= 64) ? ~0ull : (~0ull << (128 - 2 * k));
   u64 distinct_total = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
-  unsigned bp = 0;
-  unsigned seg_lo = 0, seg_hi = 0, seg_end = 0;  // (lanes 0..15) the bounds of this lane's region of the next bucket, on their way
-#define SK2_SEG_ASK(bucket)                                                                             \
-  do {                                                                                                  \
-    unsigned at_ = threadIdx.x;                                                                         \
-    asm volatile("" : "+v"(at_)); /* (no 64-bit address kept across the bucket: see mk_skcount.hip) */  \
-    at_ = (at_ < (unsigned)nseg ? at_ * p1 : 0u) + (bucket);                                            \
-    seg_lo = (unsigned)start[at_];                                                                      \
-    seg_end = (unsigned)start[at_ + 1];                                                                 \
-    seg_hi = cursor[at_];                                                                               \
-  } while (0)
-  if (blockIdx.x < p1 && threadIdx.x < 16) {
-    SK2_SEG_ASK(blockIdx.x);
-    skc_seg_publish(s_seg[0], seg_lo, seg_hi, seg_end, nseg);
-  }
-  __syncthreads();
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
-    // the bucket's regions (one, or one per XCD and a shared one): its table was built while the bucket before was counted
-    const unsigned* const seg = s_seg[bp];
-    const u64 n = __builtin_amdgcn_readfirstlane(seg[9]);
-    const unsigned bn = b + gridDim.x;
-    bool tab_done = bn >= p1;  // the next bucket's table stands in s_seg[bp ^ 1]
-    if (!tab_done && threadIdx.x < 16) SK2_SEG_ASK(bn);  // (asked for here, looked at before the bucket's first barrier)
+    const u64 lo_r = start[b], n = cursor[b] - lo_r;  // (the scatter's cursor ends where the bucket's records end)
     u64* __restrict__ my_hi = out_hi + kstart[b];
     u64* __restrict__ my_lo = out_lo + kstart[b];
     u64* __restrict__ my_cnt = out_cnt + kstart[b];
@@ -625,6 +567,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
       }
       int s = s0;
       unsigned idx = 0;
+      const Sk2Rec* __restrict__ src = part + lo_r;
       for (;;) {
         const unsigned sel_shift = SK2C_SUB_BITS - s;
         unsigned* const ovf = &s_overflow[par];
@@ -636,7 +579,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           const u64 j = jb + threadIdx.x;
           Sk2Rec rec;
           rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
-          if (j < n) rec = part[skc_seg_at(seg, (unsigned)j, nseg)];
+          if (j < n) rec = src[j];
           const int nk = (int)rec.nk;  // <= SK2_NKMAX
           win_pass += counted ? 0 : (u64)nk;
           u64 khi[SK2_NKMAX], klo[SK2_NKMAX];
@@ -703,13 +646,8 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
           if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         }
         if (qcount) sk2c_drain(tkey, tcnt, myq, qcount, qcount, ovf);  // (< 64 left)
-        if (!tab_done) {
-          if (threadIdx.x < 16) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);
-          tab_done = true;
-        }
         __syncthreads();  // A
-        // back to the regions' starts: the next chunk may inherit the regions (mk_skmer.hip)
-        if (threadIdx.x < (unsigned)nseg) cursor[threadIdx.x * p1 + b] = seg[10 + threadIdx.x] + seg[threadIdx.x];
+        if (threadIdx.x == 0) cursor[b] = lo_r;  // back to the region's start: the next chunk may inherit the regions (mk_skmer.hip)
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
         {
@@ -768,11 +706,6 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
         }
       }
     }
-    if (!tab_done) {  // (a bucket without a pass: the whole workgroup comes this way)
-      if (threadIdx.x < 16) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);
-      __syncthreads();
-    }
-    bp ^= 1;
     if (threadIdx.x == 0) nsurv[b] = emitted;
     survivors_total += emitted;
   }
@@ -854,7 +787,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
                                                                 const u64* __restrict__ kstart, u64* __restrict__ nsurv,
                                                                 MkChunkInfo* __restrict__ info, u64 min_count,
                                                                 u64* __restrict__ out_hi, u64* __restrict__ out_lo,
-                                                                u64* __restrict__ out_cnt, int k, unsigned p1, int nseg) {
+                                                                u64* __restrict__ out_cnt, int k, unsigned p1) {
   __shared__ unsigned cnt32[SK2P_CNT];
   __shared__ __attribute__((aligned(16))) ulonglong2 tkey[SK2P_SLOTS];
   __shared__ unsigned tcnt[SK2P_SLOTS];
@@ -862,7 +795,6 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
   __shared__ unsigned s_distinct[2], s_overflow[2], s_emit[2];
   __shared__ unsigned long long s_windows;
   __shared__ unsigned s_abort;
-  __shared__ __attribute__((aligned(16))) unsigned s_seg[2][SKC_SEG_WORDS];  // the bucket's regions (mk_skmer_dev.h), by bucket parity
   if (threadIdx.x == 0) { s_abort = info->part_overflow != 0; s_windows = 0; }
   __syncthreads();
   if (s_abort) return;
@@ -875,29 +807,8 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
   const u64 lomask = (k >= 64) ? ~0ull : (~0ull << (128 - 2 * k));
   const unsigned need = min_count > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)min_count;
   u64 distinct_total = 0, survivors_total = 0, nerr = 0, windows = 0, records_total = 0;
-  unsigned bp = 0;
-  unsigned seg_lo = 0, seg_hi = 0, seg_end = 0;  // (lanes 0..15) the bounds of this lane's region of the next bucket, on their way
-#define SK2_SEG_ASK(bucket)                                                                             \
-  do {                                                                                                  \
-    unsigned at_ = threadIdx.x;                                                                         \
-    asm volatile("" : "+v"(at_)); /* (no 64-bit address kept across the bucket: see mk_skcount.hip) */  \
-    at_ = (at_ < (unsigned)nseg ? at_ * p1 : 0u) + (bucket);                                            \
-    seg_lo = (unsigned)start[at_];                                                                      \
-    seg_end = (unsigned)start[at_ + 1];                                                                 \
-    seg_hi = cursor[at_];                                                                               \
-  } while (0)
-  if (blockIdx.x < p1 && threadIdx.x < 16) {
-    SK2_SEG_ASK(blockIdx.x);
-    skc_seg_publish(s_seg[0], seg_lo, seg_hi, seg_end, nseg);
-  }
-  __syncthreads();
   for (unsigned b = blockIdx.x; b < p1; b += gridDim.x) {
-    // the bucket's regions (one, or one per XCD and a shared one): its table was built while the bucket before was counted
-    const unsigned* const seg = s_seg[bp];
-    const u64 n = __builtin_amdgcn_readfirstlane(seg[9]);
-    const unsigned bn = b + gridDim.x;
-    bool tab_done = bn >= p1;  // the next bucket's table stands in s_seg[bp ^ 1]
-    if (!tab_done && threadIdx.x < 16) SK2_SEG_ASK(bn);  // (asked for here, looked at before the bucket's first barrier)
+    const u64 lo_r = start[b], n = cursor[b] - lo_r;
     u64* __restrict__ my_hi = out_hi + kstart[b];
     u64* __restrict__ my_lo = out_lo + kstart[b];
     u64* __restrict__ my_cnt = out_cnt + kstart[b];
@@ -910,6 +821,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
     } else if (n) {
       int s = 0;
       unsigned idx = 0;
+      const Sk2Rec* __restrict__ src = part + lo_r;
       for (;;) {
         const unsigned sel_shift = 32 - s;  // the sub-range is picked by the TOP bits of the hash, the counter by the low ones
         unsigned* const ovf = &s_overflow[par];
@@ -919,7 +831,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
           const u64 j = jb + threadIdx.x;
           Sk2Rec rec;
           rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
-          if (j < n) rec = part[skc_seg_at(seg, (unsigned)j, nseg)];
+          if (j < n) rec = src[j];
           const int nk = (int)rec.nk;
           win_pass += counted ? 0 : (u64)nk;
           u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
@@ -934,10 +846,6 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
             if (u < nk && (!s || (h >> sel_shift) == idx)) atomicAdd(&cnt32[h & (SK2P_CNT - 1)], 1u);
           }
         }
-        if (!tab_done) {
-          if (threadIdx.x < 16) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);
-          tab_done = true;
-        }
         __syncthreads();  // P done: the counters are final
         // ---- Q: the candidates into the exact table -- via the wave's stack (positions from ballots), 64 at a time with
         //      every lane busy: inserted one by one in the lane that found them, their LDS round trips run one after the other
@@ -947,7 +855,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
           const u64 j = jb + threadIdx.x;
           Sk2Rec rec;
           rec.r0 = rec.r1 = rec.r2 = rec.nk = 0;
-          if (j < n) rec = part[skc_seg_at(seg, (unsigned)j, nseg)];
+          if (j < n) rec = src[j];
           const int nk = (int)rec.nk;
           u64 x0 = rec.r0, x1 = rec.r1, x2 = rec.r2;
           unsigned cv[SK2_NKMAX];
@@ -993,7 +901,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
           qcount = 0;
         }
         __syncthreads();  // A: every insert of the pass is in the table
-        if (threadIdx.x < (unsigned)nseg) cursor[threadIdx.x * p1 + b] = seg[10 + threadIdx.x] + seg[threadIdx.x];  // back to the regions' starts
+        if (threadIdx.x == 0) cursor[b] = lo_r;  // back to the region's start: the next chunk may inherit the regions
         const bool over = s_overflow[par] != 0;
         if (threadIdx.x == 0) { s_distinct[par ^ 1] = 0; s_overflow[par ^ 1] = 0; s_emit[par ^ 1] = 0; }
         {
@@ -1056,11 +964,6 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
         }
       }
     }
-    if (!tab_done) {  // (a bucket without a pass: the whole workgroup comes this way)
-      if (threadIdx.x < 16) skc_seg_publish(s_seg[bp ^ 1], seg_lo, seg_hi, seg_end, nseg);
-      __syncthreads();
-    }
-    bp ^= 1;
     if (threadIdx.x == 0) nsurv[b] = emitted;
     survivors_total += emitted;
   }
@@ -1100,19 +1003,9 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     if (!exact && seq_len >= min_len) sample_log2 = want;
   }
   c->part_sampled = sample_log2 != 0;
-  // regions per bucket (mk_skmer.hip: one per XCD and a shared one when the sizes come from a sample); the walking
-  // scatter kernels -- canonical keys, MK_SCATTER_WALK -- keep one
-  const bool xseg_on = !(getenv("MK_XSEG") && atoi(getenv("MK_XSEG")) == 0);
-  const int nseg = (xseg_on && sample_log2 != 0 && !c->canonical && !getenv("MK_SCATTER_WALK") && seq_len + 64 < SK2_NOFIT) ? 9 : 1;
-  if (nseg != c->part_nseg) c->part_reuse_ok = false;  // (regions of the other layout cannot be inherited)
-  c->part_nseg = nseg;
   const bool reuse = mk_part_inherit(c, seq_len, p1_log2, min_count, sample_log2 != 0, exact);
   int rc;
-  // hist p1 | start p1 + 1 | cursor (p1 words) | khist p1 | kstart p1 + 1 | kcursor p1 | nsurv p1 | start of the 9 p1 regions + 1 | their cursors
-  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16 + 14 * p1 + 8) * sizeof(u64))) != MK_OK) return rc;
-  // (room for one record per window, the worst case with one region per bucket; nine regions -- sixteen times an eighth of
-  // the estimate and its margin -- fit unless the text yields more than about half a record per window, which then goes
-  // to the exact partition: records of two-word keys are runs of 8 windows for the most part)
+  if ((rc = mk_buf_reserve(c, c->part_meta, (7 * p1 + 16) * sizeof(u64))) != MK_OK) return rc;
   const size_t part_cap = seq_len + 64;
   if ((rc = mk_buf_reserve(c, c->part, part_cap * sizeof(Sk2Rec))) != MK_OK) return rc;
   const u64 surv_div = min_count > 1 ? (u64)min_count : 1;  // <= ceil(m / min_count) survivors among m k-mers
@@ -1131,10 +1024,6 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
   u64* kstart = khist + p1;
   u64* kcursor = kstart + p1 + 1;
   u64* nsurv = kcursor + p1;
-  if (nseg > 1) {
-    start = hist + 7 * p1 + 16;
-    cursor = (SkCursor*)(start + 9 * p1 + 8);
-  }
   if (!reuse) MK_HIP(hipMemsetAsync(hist, 0, (7 * p1 + 8) * sizeof(u64), c->stream));
   const size_t threads = div_up(seq_len, SK2_R);
   const size_t tiles = div_up(div_up(threads, (size_t)1 << sample_log2), SK2_HIST_THREADS);
@@ -1153,7 +1042,7 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
                        (const u64*)c->bad.p, info, hist, khist, p1_log2, k, threads, sample_log2);
   if (!reuse)
     mk_launch_sk_scan(c, hist, khist, start, cursor, kstart, p1_log2, sample_log2, SK2_NKMAX, surv_div, (u64)part_cap,
-                      (u64)surv_cap, sigmas, nseg);
+                      (u64)surv_cap, sigmas, 1);
   if (c->canonical)
     hipLaunchKernelGGL(mk_sk2_scatter_k<true>, sgrid, dim3(SK2_SCAT_THREADS), 0, c->stream, (const u64*)c->codes.p,
                        (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, stiles);
@@ -1169,10 +1058,10 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     const dim3 qgrid((unsigned)(qtiles < 8192 ? qtiles : 8192));
     if (three)
       hipLaunchKernelGGL((mk_sk2_scatterq_k<3, 376>), qgrid, dim3(SK2Q_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap, nseg);
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap);
     else
       hipLaunchKernelGGL((mk_sk2_scatterq_k<2, 512>), qgrid, dim3(SK2Q_THREADS), 0, c->stream, (const u64*)c->codes.p,
-                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap, nseg);
+                         (const u64*)c->bad.p, info, (const u64*)start, cursor, (Sk2Rec*)c->part.p, p1_log2, k, qtiles, qcap);
   }
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
@@ -1188,19 +1077,19 @@ int mk_launch_count_superkmer2(mk_ctx* c, size_t seq_len, uint64_t min_count, bo
     if (pre && c->canonical)
       hipLaunchKernelGGL(mk_sk2_countp_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
                          (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, nseg);
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1);
     else if (pre)
       hipLaunchKernelGGL(mk_sk2_countp_k<false>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
                          (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, nseg);
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1);
     else if (c->canonical)
       hipLaunchKernelGGL(mk_sk2_count_k<true>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
                          (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, nseg);
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
     else
       hipLaunchKernelGGL(mk_sk2_count_k<false>, dim3(grid), dim3(SK2C_THREADS), 0, c->stream, (const Sk2Rec*)c->part.p,
                          (const u64*)start, cursor, (const u64*)kstart, nsurv, info, (u64)min_count, (u64*)c->surv_keys.p,
-                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint, nseg);
+                         (u64*)c->surv_keys2.p, (u64*)c->surv_cnts.p, k, (unsigned)p1, c->dup_hint, c->nk_hint);
   }
   mk_prof_end(c);
   MK_HIP(hipGetLastError());
