@@ -23,6 +23,21 @@ __device__ __forceinline__ u64 bad_window(const u64* __restrict__ bad, size_t p0
   return (b0 >> bo) | (bad[bi + 1] << (64 - bo));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts -- vector instructions only.
+// (A scan written with __shfl_up is six DEPENDENT ds_bpermute round trips through the LDS, ~120 clocks each, plus the
+// address arithmetic and selects around them: tools/valu_probe.hip.)  Lanes that a step has no source for add 0.
+__device__ __forceinline__ unsigned mk_wave_scan_incl(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8: every row of 16 is scanned
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+// the value lane 63 holds, in every lane (v_readlane: no trip through the LDS)
+__device__ __forceinline__ unsigned mk_wave_last(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
+
 __device__ __forceinline__ void wave_add(u64* target, u64 mine) {
   for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
   if ((threadIdx.x & 63) == 0 && mine) atomicAdd(target, mine);

@@ -21,6 +21,7 @@
 //   pass 3 mk_fparse_emit  recompute masks, compact the kept bytes into LDS at the alignment of
 //                          their destination, write them out with aligned 16-byte stores
 #include "mk_common.h"
+#include "mk_device.h"
 
 typedef unsigned long long u64;
 
@@ -100,8 +101,8 @@ __device__ __forceinline__ unsigned wave_step(unsigned nl, unsigned gt, unsigned
                                               unsigned& last_nl) {
   const int lane = threadIdx.x & 63;
   const unsigned my_last_nl = (nl >> 15) & 1u;
-  unsigned prev = __shfl_up(my_last_nl, 1);
-  if (lane == 0) prev = prev_nl;
+  // (the lane before this one: a DPP wave shift right by one; lane 0 keeps `old` = prev_nl)
+  const unsigned prev = (unsigned)__builtin_amdgcn_update_dpp((int)prev_nl, (int)my_last_nl, 0x138, 0xf, 0xf, false);  // wave_shr:1
   const unsigned ls = ((nl << 1) | prev) & 0xFFFFu;  // line-start bits
   const unsigned start = ls & gt;                    // '>' at a line start
   unsigned hout0;
@@ -117,8 +118,8 @@ __device__ __forceinline__ unsigned wave_step(unsigned nl, unsigned gt, unsigned
   sep = start;
   out = ((~H & ~nl & ~st) | start) & 0xFFFFu;
   bad_low = low & ~H;
-  last_nl = __shfl(my_last_nl, 63);
-  return __shfl(hout, 63);
+  last_nl = mk_wave_last(my_last_nl);
+  return mk_wave_last(hout);
 }
 
 // zero_codes / zero_bad (fused nucleotide pack only): the emit pass ORs partial words in, so the packed words and the
@@ -321,12 +322,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
     const unsigned cnt = __popc(out);
     nbad -= (int)__popc(sep);
     nhi += __popc(hi & out & ~sep);
-    unsigned inc = cnt;  // inclusive scan over the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned up = __shfl_up(inc, d);
-      if (lane >= d) inc += up;
-    }
+    const unsigned inc = mk_wave_scan_incl(cnt);  // inclusive scan over the wave
     unsigned at = shift + filled + inc - cnt;
 #define FP_BYTE(j) ((uint8_t)(((j) < 4 ? v.x : ((j) < 8 ? v.y : ((j) < 12 ? v.z : v.w))) >> (8 * ((j) & 3))))
     if (out == 0xFFFFu && sep == 0) {
@@ -352,7 +348,7 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_emit(const uint8_t* __re
       for (unsigned sp = sep; sp; sp &= sp - 1) lds[at + __popc(out & ((1u << (__ffs(sp) - 1)) - 1u))] = (uint8_t)MK_SEP;
     }
 #undef FP_BYTE
-    filled += __shfl(inc, 63);
+    filled += mk_wave_last(inc);
   }
   // ---- write out: LDS offset == destination address (mod 16), so full 16-byte pieces are aligned
   __builtin_amdgcn_wave_barrier();

@@ -566,18 +566,18 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
           static_assert(PER % 2 == 0, "the sweep takes slot pairs");
           unsigned ec[PER];
           unsigned keep = 0;  // bit q: slot q of this thread survives
-          unsigned occ = 0;
+          unsigned occ = 0;   // occupied slots of the wave (wave-uniform: counted with ballots, not summed over the lanes
+                              // by six dependent shuffles -- the sweep is short and nothing hides their round trips)
 #pragma unroll
           for (int q = 0; q < PER; q += 2) {
             const unsigned i = (q * SKC_THREADS + 2 * threadIdx.x);
             const uint2 cp = *reinterpret_cast<const uint2*>(&tcnt[i]);
             ec[q] = cp.x;
             ec[q + 1] = cp.y;
-            occ += (cp.x != 0) + (cp.y != 0);
+            occ += (unsigned)__popcll(__ballot(cp.x != 0)) + (unsigned)__popcll(__ballot(cp.y != 0));
             keep |= (!over && cp.x && (u64)cp.x >= min_count) ? (1u << q) : 0u;
             keep |= (!over && cp.y && (u64)cp.y >= min_count) ? (2u << q) : 0u;
           }
-          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
           if (FUSED && keep) {
             const unsigned mine = (unsigned)__popc(keep);

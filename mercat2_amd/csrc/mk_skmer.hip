@@ -423,13 +423,8 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
       if (lane == 63) pk_x[st][wv][64] = ww1;
       const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, nkmax);
       const unsigned cnt = __popc(s2);
-      unsigned inc = cnt;  // inclusive scan over the wave
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned up = __shfl_up(inc, d);
-        if (lane >= d) inc += up;
-      }
-      const unsigned total = __shfl(inc, 63);
+      const unsigned inc = mk_wave_scan_incl(cnt);  // inclusive scan over the wave
+      const unsigned total = mk_wave_last(inc);
       unsigned* const myq = queue[st][wv];
       if (total <= qcap) {  // (qcap <= SKQ_QCAP; tests lower it to walk some or all waves)
         unsigned todo = s2, at = inc - cnt;

@@ -361,13 +361,8 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
       }
       const unsigned s2 = sk_cut_starts(runs.starts, runs.valid, SK2_NKMAX);
       const unsigned cnt = __popc(s2);
-      unsigned inc = cnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned up = __shfl_up(inc, d);
-        if (lane >= d) inc += up;
-      }
-      const unsigned total = __shfl(inc, 63);
+      const unsigned inc = mk_wave_scan_incl(cnt);  // inclusive scan over the wave (DPP: mk_device.h)
+      const unsigned total = mk_wave_last(inc);
       unsigned* const myq = queue[st][wv];
       if (total <= qcap) {
         unsigned todo = s2, at = inc - cnt;

@@ -250,12 +250,11 @@ __device__ __forceinline__ unsigned skc_seg_at(const unsigned* tab, unsigned j, 
 __device__ __forceinline__ void skc_seg_publish(unsigned* tab, unsigned seg_lo, unsigned seg_hi, unsigned seg_end, int nseg) {
   asm volatile("" : "+v"(seg_lo), "+v"(seg_hi), "+v"(seg_end));  // (nothing computed from the bounds before this point: they are waited for HERE)
   const unsigned x = threadIdx.x & 15u, cnt = x < (unsigned)nseg ? (seg_hi < seg_end ? seg_hi : seg_end) - seg_lo : 0u;
-  unsigned inc = cnt;
-#pragma unroll
-  for (int d = 1; d < 16; d <<= 1) {
-    const unsigned up = __shfl_up(inc, d, 16);
-    if (x >= (unsigned)d) inc += up;
-  }
+  unsigned inc = cnt;  // inclusive scan over the sixteen lanes: one DPP row (mk_wave_scan_incl's first four steps)
+  inc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+  inc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+  inc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+  inc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
   if (x < SKC_SEG_MAX) {
     tab[x] = inc - cnt;
     tab[10 + x] = seg_lo - (inc - cnt);

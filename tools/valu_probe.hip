@@ -40,6 +40,17 @@ BODY(k_add3, "v_add3_u32 %0, %0, %1, %1", unsigned)
 BODY(k_perm, "v_perm_b32 %0, %0, %1, %1", unsigned)
 BODY(k_readlane, "v_readlane_b32 s22, %0, 3", unsigned)
 BODY(k_writelane, "v_writelane_b32 %0, s22, 3", unsigned)
+BODY(k_cmp_cnd_vcc, "v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc", unsigned)
+BODY(k_cmp_cnd_sgpr, "v_cmp_lt_u32 s[20:21], %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]", unsigned)
+BODY(k_cnd_e64_vcc, "v_cndmask_b32_e64 %0, %0, %1, vcc", unsigned)
+BODY(k_addc_vcc, "v_addc_co_u32 %0, vcc, %0, %1, vcc", unsigned)
+BODY(k_mov_dpp, "v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf", unsigned)
+BODY(k_add_dpp, "v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf", unsigned)
+BODY(k_and_b32, "v_and_b32 %0, %0, %1", unsigned)
+BODY(k_lshl_b32, "v_lshlrev_b32 %0, 3, %0", unsigned)
+BODY(k_min_u32, "v_min_u32 %0, %0, %1", unsigned)
+BODY(k_mov_b32, "v_mov_b32 %0, %1", unsigned)
+BODY(k_sub_u32, "v_sub_u32 %0, %0, %1", unsigned)
 BODY(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %1, %0", unsigned)
 BODY(k_sdwa_and, "v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD", unsigned)
 BODY(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1", unsigned)
@@ -81,6 +92,7 @@ int main() {
 #define R(k) run(#k, k, d, mhz)
   R(k_add_u32); R(k_xor_b32); R(k_mul_u24); R(k_mul_lo); R(k_alignbit); R(k_bfe); R(k_lshl_add); R(k_mad_u24);
   R(k_cndmask_s); R(k_cndmask_01); R(k_cndmask_only1); R(k_and_or); R(k_add3); R(k_perm); R(k_readlane); R(k_writelane);
+  R(k_cmp_cnd_vcc); R(k_cmp_cnd_sgpr); R(k_cnd_e64_vcc); R(k_addc_vcc); R(k_mov_dpp); R(k_add_dpp); R(k_and_b32); R(k_lshl_b32); R(k_min_u32); R(k_mov_b32); R(k_sub_u32);
   R(k_lshl_b64); R(k_lshr_b64); R(k_lshl_add_u64); R(k_mov_b64); R(k_cmp_eq_u64); R(k_cmp_eq_u32); R(k_cmp_lt_i32_s); R(k_cndmask);
   R(k_mbcnt); R(k_sdwa_and); R(k_pk_add_u16);
   return 0;
