@@ -35,6 +35,8 @@ __device__ __forceinline__ unsigned mk_wave_scan_incl(unsigned v) {
   v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return v;
 }
+// sum over the wave, in every lane
+__device__ __forceinline__ unsigned mk_wave_sum(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)mk_wave_scan_incl(v), 63); }
 // the value lane 63 holds, in every lane (v_readlane: no trip through the LDS)
 __device__ __forceinline__ unsigned mk_wave_last(unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, 63); }
 

@@ -168,11 +168,9 @@ __global__ __launch_bounds__(FP_THREADS) void mk_fparse_summ(const uint8_t* __re
     any_nl |= (__ballot(nl != 0) != 0) ? 1u : 0u;
     prev_nl = last_nl;
   }
-  for (int d = 32; d > 0; d >>= 1) {
-    c0 += __shfl_down(c0, d);
-    c1 += __shfl_down(c1, d);
-    seps += __shfl_down(seps, d);
-  }
+  c0 = mk_wave_sum(c0);  // (DPP: mk_device.h)
+  c1 = mk_wave_sum(c1);
+  seps = mk_wave_sum(seps);
   (void)flag_low;
   if (lane == 0) {
     entries[wave].a = any_nl | (s0 << 1) | (seps << 2);

@@ -954,7 +954,7 @@ __global__ __launch_bounds__(SKC_THREADS) void mk_sk_countp_k(const ulonglong2* 
             occ += (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
             *reinterpret_cast<uint4*>(&cnt32[i]) = make_uint4(0u, 0u, 0u, 0u);
           }
-          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          occ = mk_wave_sum(occ);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
           constexpr int PER = SKP_SLOTS / SKC_THREADS;
           unsigned ec[PER];

@@ -659,7 +659,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_count_k(const Sk2Rec* __r
             if (over || (u64)ec[q] < min_count) ec[q] = 0;
             mine += ec[q] != 0;
           }
-          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          occ = mk_wave_sum(occ);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
           if (mine) {
             const unsigned at = emitted + atomicAdd(&s_emit[par], mine);
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(SK2C_THREADS) void mk_sk2_countp_k(const Sk2Rec* __
             occ += (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
             *reinterpret_cast<uint4*>(&cnt32[i]) = make_uint4(0u, 0u, 0u, 0u);
           }
-          for (int d = 32; d > 0; d >>= 1) occ += __shfl_down(occ, d);
+          occ = mk_wave_sum(occ);
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
           // exact table: emit what reached min_count, clear
           constexpr int PER = SK2P_SLOTS / SK2C_THREADS;
