@@ -579,10 +579,22 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
             keep |= (!over && cp.y && (u64)cp.y >= min_count) ? (2u << q) : 0u;
           }
           if (lane == 0 && occ && !over) atomicAdd(&s_distinct[par], occ);
-          if (FUSED && keep) {
+          // (places in the list: one LDS add per WAVE -- its lanes' counts scanned with DPP -- instead of two adds to the
+          // same two words from every thread that holds a survivor, which the LDS works off one after the other)
+          unsigned pos0 = 0;
+          if (FUSED) {
             const unsigned mine = (unsigned)__popc(keep);
-            atomicAdd(&s_emit[par], mine);  // (the chunk's survivor count: a statistic here)
-            const unsigned pos0 = atomicAdd(&s_npend[f_cur ^ 1], mine);
+            const unsigned inc = mk_wave_scan_incl(mine), total = mk_wave_last(inc);
+            if (total) {  // (wave-uniform)
+              unsigned base = 0;
+              if (lane == 0) {
+                atomicAdd(&s_emit[par], total);  // (the chunk's survivor count: a statistic here)
+                base = atomicAdd(&s_npend[f_cur ^ 1], total);
+              }
+              pos0 = (unsigned)__builtin_amdgcn_readfirstlane((int)base) + inc - mine;
+            }
+          }
+          if (FUSED && keep) {
             unsigned o = 0;
 #pragma unroll
             for (int q = 0; q < PER; ++q) {
