@@ -872,7 +872,8 @@ static int process_chunk(mk_ctx* c, const uint8_t* d_raw, size_t n, u64 min_coun
       rc = mk_launch_import_regions(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p,
                                     meta + 4 * p1 + 1, meta + 6 * p1 + 2, p1, (size_t)c->h_info->survivors);
     } else {
-      rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors);
+      // (a chunk's survivors from the direct-index / 8-byte-key paths: each key once)
+      rc = mk_launch_import_pairs(c, (const uint64_t*)c->surv_keys.p, (const uint64_t*)c->surv_cnts.p, (size_t)c->h_info->survivors, true);
     }
     mk_prof_end(c);
     if (rc) return rc;

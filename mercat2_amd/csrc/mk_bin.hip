@@ -19,8 +19,10 @@
 #include <cstdlib>
 
 #define BIN_THREADS 512
-#define BIN_SUBT 2
-#define BIN_MAX_NB 8192   // buckets (2^13) at most; bins per bucket 2^low <= 8192
+#define BINC_THREADS 1024  // the count kernel: one workgroup per CU (128 KB of bins)
+#define BIN_MAX_NB 8192   // (histogram / scan kernels: buckets they can hold)
+#define BIN_SC_NB 2048    // buckets at most: 1024, or 2048 for keys of 26 bits
+#define BIN_MAX_LOW 15    // bins per bucket 2^low <= 32768 (128 KB of 32-bit counters in the count kernel's LDS)
 
 static size_t bin_div_up(size_t a, size_t b) { return (a + b - 1) / b; }
 
@@ -98,65 +100,80 @@ __global__ __launch_bounds__(1024) void mk_bin_scan_k(const unsigned* __restrict
   }
 }
 
+// A tile's items are first SORTED BY BUCKET IN LDS and then written run by run.  Stored straight from the lanes that
+// found them (the first version) every two-byte item was a memory transaction of its own -- 64 lanes, 64 buckets, 64
+// lines per store instruction -- and the scatter ran at the L2's transaction rate, 610 us for 60 M protein 5-mers, wherever
+// the lines went (tile classes with per-XCD queues changed nothing).  With <= 2048 buckets a tile of 18 K items holds runs
+// of 9-18 items per bucket: the copy-out's lanes write neighbouring addresses, a store instruction touches 4-8 lines.
 template <int BITS, int SPW, int WPT>
 __global__ __launch_bounds__(BIN_THREADS) void mk_bin_scatter_k(const u64* __restrict__ codes, const u64* __restrict__ bad,
                                                                 const MkChunkInfo* __restrict__ info, unsigned* __restrict__ cursor,
                                                                 unsigned short* __restrict__ items, int low, unsigned nb, int k,
                                                                 size_t ntiles, int canon) {
-  // lh[b]: pass 1 counts the tile's windows of bucket b; after the reservation it holds the item index at which the
-  // tile's run in that bucket starts, and pass 2's add hands out base + rank in one step
-  __shared__ unsigned lh[BIN_MAX_NB];
+  constexpr unsigned TILE_ITEMS = BIN_THREADS * SPW * WPT;
+  __shared__ unsigned cnt[BIN_SC_NB];    // pass 1: the tile's windows per bucket; then the running place inside the stage
+  __shared__ unsigned off0[BIN_SC_NB];   // where the bucket's run starts in the stage
+  __shared__ unsigned gbase[BIN_SC_NB];  // where it starts in the item buffer (reserved with one add per bucket and tile)
+  __shared__ unsigned stage[TILE_ITEMS]; // bucket << 16 | low bits of the key, sorted by bucket
+  __shared__ unsigned wsum[BIN_THREADS / 64];
   const size_t seq_len = info->seq_len;
   const u64 kmask = (1ull << k) - 1;
   const unsigned lowmask = (1u << low) - 1;
-  for (unsigned i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
-  __syncthreads();
+  const unsigned per = nb / BIN_THREADS;  // buckets per thread in the scan (nb is 1024 or 2048: 2 or 4)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-#pragma unroll 1
-    for (int st = 0; st < BIN_SUBT; ++st) {
-      const size_t t = (tile * BIN_SUBT + st) * BIN_THREADS + threadIdx.x;
-      if (t * (size_t)(SPW * WPT) < seq_len)
-        bin_windows<BITS, SPW, WPT>(codes, bad, t, k, kmask, canon != 0, [&](unsigned key) { atomicAdd(&lh[key >> low], 1u); });
-    }
+    for (unsigned i = threadIdx.x; i < nb; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    // (regions are exact: the histogram counted the same windows)
-    if (nb == BIN_MAX_NB) {  // all of a thread's reservations in flight together (one round trip instead of sixteen)
-      constexpr int NBT = BIN_MAX_NB / BIN_THREADS;
-      unsigned v[NBT], r[NBT];
+    const size_t t = tile * BIN_THREADS + threadIdx.x;
+    const bool mine = t * (size_t)(SPW * WPT) < seq_len;
+    if (mine) bin_windows<BITS, SPW, WPT>(codes, bad, t, k, kmask, canon != 0, [&](unsigned key) { atomicAdd(&cnt[key >> low], 1u); });
+    __syncthreads();
+    // reservations (regions are exact: the histogram counted the same windows) and the exclusive scan of the counts
+    unsigned v[4] = {0, 0, 0, 0}, sum = 0;
 #pragma unroll
-      for (int i = 0; i < NBT; ++i) v[i] = lh[threadIdx.x + i * BIN_THREADS];
-#pragma unroll
-      for (int i = 0; i < NBT; ++i) r[i] = v[i] ? atomicAdd(&cursor[threadIdx.x + i * BIN_THREADS], v[i]) : 0u;
-#pragma unroll
-      for (int i = 0; i < NBT; ++i) lh[threadIdx.x + i * BIN_THREADS] = r[i];
-    } else {
-      for (unsigned b = threadIdx.x; b < nb; b += BIN_THREADS) {
-        const unsigned v = lh[b];
-        if (v) lh[b] = atomicAdd(&cursor[b], v);
+    for (unsigned q = 0; q < 4; ++q)
+      if (q < per) {
+        const unsigned b = threadIdx.x * per + q;
+        v[q] = cnt[b];
+        gbase[b] = v[q] ? atomicAdd(&cursor[b], v[q]) : 0u;
+        sum += v[q];
       }
-    }
+    const unsigned inc = mk_wave_scan_incl(sum);
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-#pragma unroll 1
-    for (int st = 0; st < BIN_SUBT; ++st) {
-      const size_t t = (tile * BIN_SUBT + st) * BIN_THREADS + threadIdx.x;
-      if (t * (size_t)(SPW * WPT) < seq_len)
-        bin_windows<BITS, SPW, WPT>(codes, bad, t, k, kmask, canon != 0, [&](unsigned key) {
-          const unsigned at = atomicAdd(&lh[key >> low], 1u);
-          items[at] = (unsigned short)(key & lowmask);
-        });
-    }
+    unsigned run = inc - sum;
+    for (int w = 0; w < wv; ++w) run += wsum[w];
+#pragma unroll
+    for (unsigned q = 0; q < 4; ++q)
+      if (q < per) {
+        const unsigned b = threadIdx.x * per + q;
+        off0[b] = run;
+        cnt[b] = run;
+        run += v[q];
+      }
+    unsigned total = 0;
+    for (int w = 0; w < BIN_THREADS / 64; ++w) total += wsum[w];
     __syncthreads();
-    for (unsigned i = threadIdx.x; i < nb; i += blockDim.x) lh[i] = 0;
+    if (mine)
+      bin_windows<BITS, SPW, WPT>(codes, bad, t, k, kmask, canon != 0, [&](unsigned key) {
+        const unsigned b = key >> low;
+        stage[atomicAdd(&cnt[b], 1u)] = (b << 16) | (key & lowmask);
+      });
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < total; i += BIN_THREADS) {
+      const unsigned e = stage[i], b = e >> 16;
+      items[(size_t)gbase[b] + (i - off0[b])] = (unsigned short)e;
+    }
     __syncthreads();
   }
 }
 
 // Persistent: workgroup w takes buckets w, w + gridDim.x, ...  Survivors go to out_keys / out_cnts at positions reserved
 // with one add to info->survivors per bucket (the import of mk_table.hip takes them from there).
-__global__ __launch_bounds__(BIN_THREADS) void mk_bin_count_k(const unsigned short* __restrict__ items, const unsigned* __restrict__ start,
+__global__ __launch_bounds__(BINC_THREADS) void mk_bin_count_k(const unsigned short* __restrict__ items, const unsigned* __restrict__ start,
                                                               MkChunkInfo* __restrict__ info, u64 min_count, u64* __restrict__ out_keys,
                                                               u64* __restrict__ out_cnts, int low, unsigned nb) {
-  __shared__ unsigned bins[BIN_MAX_NB];
+  __shared__ unsigned bins[1 << BIN_MAX_LOW];
   __shared__ unsigned s_keep[2], s_occ[2];
   __shared__ unsigned long long s_base[2];
   const unsigned nbins = 1u << low;
@@ -176,7 +193,15 @@ __global__ __launch_bounds__(BIN_THREADS) void mk_bin_count_k(const unsigned sho
     if (threadIdx.x < h) atomicAdd(&bins[src[threadIdx.x]], 1u);
     const unsigned quads = (n - h) / 4;
     const ushort4* __restrict__ q4 = reinterpret_cast<const ushort4*>(src + h);
-    for (unsigned i = threadIdx.x; i < quads; i += BIN_THREADS) {
+    unsigned i = threadIdx.x;
+    for (; i + 3 * BINC_THREADS < quads; i += 4 * BINC_THREADS) {  // (four loads in flight per lane)
+      const ushort4 v0 = q4[i], v1 = q4[i + BINC_THREADS], v2 = q4[i + 2 * BINC_THREADS], v3 = q4[i + 3 * BINC_THREADS];
+      atomicAdd(&bins[v0.x], 1u); atomicAdd(&bins[v0.y], 1u); atomicAdd(&bins[v0.z], 1u); atomicAdd(&bins[v0.w], 1u);
+      atomicAdd(&bins[v1.x], 1u); atomicAdd(&bins[v1.y], 1u); atomicAdd(&bins[v1.z], 1u); atomicAdd(&bins[v1.w], 1u);
+      atomicAdd(&bins[v2.x], 1u); atomicAdd(&bins[v2.y], 1u); atomicAdd(&bins[v2.z], 1u); atomicAdd(&bins[v2.w], 1u);
+      atomicAdd(&bins[v3.x], 1u); atomicAdd(&bins[v3.y], 1u); atomicAdd(&bins[v3.z], 1u); atomicAdd(&bins[v3.w], 1u);
+    }
+    for (; i < quads; i += BINC_THREADS) {
       const ushort4 v = q4[i];
       atomicAdd(&bins[v.x], 1u);
       atomicAdd(&bins[v.y], 1u);
@@ -189,7 +214,7 @@ __global__ __launch_bounds__(BIN_THREADS) void mk_bin_count_k(const unsigned sho
     __syncthreads();
     // sweep: count the bins in use and the ones that stay, reserve the survivors' places, write them, clear
     unsigned mine = 0, occ = 0;
-    for (unsigned i = threadIdx.x; i < nbins; i += BIN_THREADS) {
+    for (unsigned i = threadIdx.x; i < nbins; i += BINC_THREADS) {
       const unsigned v = bins[i];
       occ += v != 0;
       mine += (v && (u64)v >= min_count) ? 1u : 0u;
@@ -205,7 +230,7 @@ __global__ __launch_bounds__(BIN_THREADS) void mk_bin_count_k(const unsigned sho
     __syncthreads();
     if (mine) {
       u64 at = s_base[par] + at0;
-      for (unsigned i = threadIdx.x; i < nbins; i += BIN_THREADS) {
+      for (unsigned i = threadIdx.x; i < nbins; i += BINC_THREADS) {
         const unsigned v = bins[i];
         if (v && (u64)v >= min_count) {
           out_keys[at] = ((u64)b << low) | (u64)i;
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(BIN_THREADS) void mk_bin_count_k(const unsigned sho
         }
       }
     }
-    for (unsigned i = threadIdx.x; i < nbins; i += BIN_THREADS) bins[i] = 0;
+    for (unsigned i = threadIdx.x; i < nbins; i += BINC_THREADS) bins[i] = 0;
     __syncthreads();
     par ^= 1;
   }
@@ -236,7 +261,7 @@ int mk_launch_count_binned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
   if (seq_len >= 0xFFFFFF00ull) { c->err = "mk_launch_count_binned: chunk of 4 G symbols or more"; return MK_ERR_RANGE; }
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
   const int kb = c->bits * c->k;
-  const int low = std::max(6, kb - 13);
+  const int low = std::min(BIN_MAX_LOW, std::max(6, kb - 10));  // 1024 buckets (2048 for 26 bits), <= 32768 bins each
   const unsigned nb = 1u << (kb - low);
   c->p1_log2 = kb - low;
   int rc;
@@ -256,7 +281,7 @@ int mk_launch_count_binned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
 #define BIN_LAUNCH(BITS, SPW, WPT)                                                                                          \
   do {                                                                                                                      \
     const size_t threads = bin_div_up(seq_len, (size_t)(SPW) * (WPT));                                                      \
-    const size_t tiles = bin_div_up(threads, (size_t)BIN_THREADS * BIN_SUBT);                                               \
+    const size_t tiles = bin_div_up(threads, (size_t)BIN_THREADS);                                                          \
     const unsigned hgrid = (unsigned)std::min<size_t>(bin_div_up(threads, BIN_THREADS), (size_t)ncu * 4);                   \
     hipLaunchKernelGGL((mk_bin_hist_k<BITS, SPW, WPT>), dim3(hgrid), dim3(BIN_THREADS), 0, c->stream, (const u64*)c->codes.p, \
                        (const u64*)c->bad.p, info, hist, low, nb, c->k, threads, c->canonical);                             \
@@ -270,7 +295,7 @@ int mk_launch_count_binned(mk_ctx* c, size_t seq_len, uint64_t min_count) {
 #undef BIN_LAUNCH
   mk_prof_end(c);
   mk_prof_begin(c, MK_K_COUNT);
-  hipLaunchKernelGGL(mk_bin_count_k, dim3((unsigned)std::min<size_t>(nb, (size_t)ncu * 4)), dim3(BIN_THREADS), 0, c->stream,
+  hipLaunchKernelGGL(mk_bin_count_k, dim3((unsigned)std::min<size_t>(nb, (size_t)ncu)), dim3(BINC_THREADS), 0, c->stream,
                      (const unsigned short*)c->part.p, (const unsigned*)start, info, (u64)min_count, (u64*)c->surv_keys.p,
                      (u64*)c->surv_cnts.p, low, nb);
   mk_prof_end(c);

@@ -274,7 +274,7 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count);
 int mk_launch_merge_table64(mk_ctx* c, const MkSlot* from, size_t from_slots);
 int mk_launch_rehash64(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
 int mk_launch_rehash_ref(mk_ctx* c, const MkSlot* from, size_t from_slots, MkSlot* to, size_t to_slots);
-int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows);
+int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows, bool distinct = false);
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
                              const uint64_t* nsurv, size_t p1, size_t survivors);
 int mk_launch_import_ref(mk_ctx* c, const uint8_t* d_kmers, const uint64_t* d_counts, size_t rows);

@@ -186,6 +186,20 @@ __global__ void mk_import_regions_k(const u64* __restrict__ keys, const u64* __r
   block_add(new_rows, fresh);
 }
 
+// Pairs that are DISTINCT within the launch (a chunk's survivors from the direct-index and the 8-byte-key paths: every
+// key is counted in one bucket) into a table nobody else writes meanwhile: the plain-store upsert above.
+__global__ void mk_import_pairs_distinct_k(const u64* __restrict__ keys, const u64* __restrict__ cnts, size_t rows,
+                                           MkSlot* __restrict__ run, RunAddr run_mask, u64* __restrict__ new_rows, u64* __restrict__ side) {
+  u64 fresh = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+    const u64 key = keys[i], cnt = cnts[i];
+    if (!cnt) continue;
+    if (key == MK_EMPTY) atomicAdd(side, cnt);
+    else fresh += upsert64_distinct(run, run_mask, key, cnt) ? 1 : 0;
+  }
+  block_add(new_rows, fresh);
+}
+
 int mk_launch_import_regions(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* kstart,
                              const uint64_t* nsurv, size_t p1, size_t survivors) {
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
@@ -655,9 +669,16 @@ int mk_launch_accumulate(mk_ctx* c, uint64_t min_count) {
   return MK_OK;
 }
 
-int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows) {
+int mk_launch_import_pairs(mk_ctx* c, const uint64_t* d_keys, const uint64_t* d_counts, size_t rows, bool distinct) {
   if (!rows) return MK_OK;
   MkChunkInfo* info = (MkChunkInfo*)c->info.p;
+  static const bool always_atomic = getenv("MK_IMPORT_ATOMIC") != nullptr;
+  if (distinct && c->mode == MK_MODE_HASH64 && !always_atomic && c->sharers.empty()) {
+    hipLaunchKernelGGL(mk_import_pairs_distinct_k, dim3(grid_for(rows, 256, 8192)), dim3(256), 0, c->stream, (const u64*)d_keys,
+                       (const u64*)d_counts, rows, (MkSlot*)c->run.p, run_addr(c, c->run_slots), &info->new_rows, &info->side);
+    MK_HIP(hipGetLastError());
+    return MK_OK;
+  }
   if (c->mode == MK_MODE_DENSE) {
     const size_t nbins = (size_t)1 << (c->bits * c->k);
     hipLaunchKernelGGL(mk_import_bins_k, dim3(grid_for(rows)), dim3(256), 0, c->stream, (const u64*)d_keys,
