@@ -400,7 +400,12 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
   const unsigned lhn = p1 < (unsigned)SK_LH ? p1 : (unsigned)SK_LH;  // counters in use
   const unsigned nround = p1 / lhn;                                  // 1, or 2 with 2^14 buckets
   const size_t seq_len = info->seq_len;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  // (the wave's number, computed again at every use from an empty asm: kept in a register -- with the queue and word-row
+  // addresses the compiler derives from it for every sub-tile -- it was spilled to scratch under the kernel's 128 registers
+  // and loaded back once per sub-tile)
+#define wv sk_wave_id()
+  auto sk_wave_id = [&]() { int w = (int)threadIdx.x; asm volatile("" : "+v"(w)); return w >> 6; };
   for (unsigned i = threadIdx.x; i < lhn; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   u64 tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, tF = 0, t0 = 0, ntile = 0;
@@ -610,6 +615,7 @@ __global__ __launch_bounds__(SKQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #endif
   if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
+#undef wv
 
 #ifdef SK_EXP_SORT
 // EXPERIMENT (timing only, not in the product build): the records of every bucket sorted by their number of windows,

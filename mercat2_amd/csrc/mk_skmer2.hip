@@ -334,7 +334,9 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
   constexpr int NB = SK2_MAX_P1 / SK2Q_THREADS;
   const unsigned p1 = 1u << p1_log2;
   const size_t seq_len = info->seq_len;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+#define wv sk2_wave_id()  /* (computed again at every use, as in mk_sk_scatterq_k: no spill of the addresses derived from it) */
+  auto sk2_wave_id = [&]() { int w = (int)threadIdx.x; asm volatile("" : "+v"(w)); return w >> 6; };
   for (unsigned i = threadIdx.x; i < p1; i += blockDim.x) lh[i] = 0;
   __syncthreads();
   for (size_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(SK2Q_THREADS) __attribute__((amdgpu_waves_per_eu(4,
   }
   if (spilled) atomicOr(&info->part_overflow, 4ull);
 }
+#undef wv
 
 // ------------------------------------------------------------------------------------- count
 // Slot hash of a two-word key: six full-rate 24-bit multiplies over its 24-bit pieces (a 32-bit multiply issues at a
