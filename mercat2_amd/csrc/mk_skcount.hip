@@ -134,11 +134,16 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
     bool placed = false;
 #pragma unroll 1
     for (int probe = 0; probe < SKC_MAX_PROBE; ++probe) {
+#ifdef SKC_DRAIN_READ_FIRST  // (A/B: look before claiming -- two trips through the LDS for a free slot)
       u64 cur = tkey[slot];
       if (cur == MK_EMPTY) {
         cur = atomicCAS(&tkey[slot], MK_EMPTY, key);
         if (cur == MK_EMPTY) cur = key;
       }
+#else
+      u64 cur = atomicCAS(&tkey[slot], MK_EMPTY, key);  // claim-or-compare in one trip, as in the insert round
+      if (cur == MK_EMPTY) cur = key;
+#endif
       if (cur == key) {
         atomicAdd(&tcnt[slot], 1u);
         placed = true;
