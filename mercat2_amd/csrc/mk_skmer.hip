@@ -804,8 +804,10 @@ int mk_launch_count_superkmer(mk_ctx* c, size_t seq_len, uint64_t min_count, boo
   const bool xseg_on = !(getenv("MK_XSEG") && atoi(getenv("MK_XSEG")) == 0);
   static const bool walked_env = getenv("MK_SCATTER_WALK") != nullptr;
   static const bool force_pre = getenv("MK_FORCE_PREFILTER") != nullptr;  // (that count kernel reads one region per bucket)
+  // (chunks of up to 1 GiB: the nine regions take room for two records per window, 32 bytes per byte of text -- a sample
+  // counted unchunked, -s 0, keeps the single region and its 16)
   const int nseg = (xseg_on && sample_log2 != 0 && !walked_env && !force_pre && p1_log2 <= SK_LH_LOG2 &&
-                    2 * (u64)seq_len + 64 < 0xFF000000ull) ? 9 : 1;  // (32-bit cursors over twice the room)
+                    seq_len <= ((size_t)1 << 30)) ? 9 : 1;
   if (nseg != c->part_nseg) c->part_reuse_ok = false;  // (regions of the other layout cannot be inherited)
   c->part_nseg = nseg;
   const bool reuse = mk_part_inherit(c, seq_len, p1_log2, min_count, sample_log2 != 0, exact);
