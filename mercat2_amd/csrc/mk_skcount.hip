@@ -466,9 +466,15 @@ __global__ __launch_bounds__(SKC_LB) void mk_sk_count_k(const ulonglong2* __rest
 #ifdef SKC_UNCOND
                 atomicAdd(&tcnt[sl[u]], ok ? 1u : 0u);
 #else
+#ifndef SKC_ABL_NOADD  // (timing ablation only, counts are wrong: 306 -> 274 us per S2 chunk)
                 if (ok) atomicAdd(&tcnt[sl[u]], 1u);
 #endif
+#endif
+#ifdef SKC_ABL_NODEFER  // (timing ablation only, keys that miss their home slot are dropped: 306 -> 212 us -- the stack
+                on[u] = false;   // and the probing loop are a third of the kernel; trying the next slot inside the round as well
+#else                    // -- a second batch of eight compare-and-swaps and adds -- measured 337 us: the round got dearer by more)
                 on[u] = on[u] && !ok;  // from here on: the key did not settle at its home slot
+#endif
               }
               // deferred keys -> the wave's stack (positions from ballots: no atomic), four slots at a time
               // so that the stack never holds more than SKC_QCAP; full groups of 64 are probed right away
