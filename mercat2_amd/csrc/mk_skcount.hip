@@ -128,6 +128,9 @@ __device__ __forceinline__ void skc_drain(u64* tkey, unsigned* tcnt, const u64* 
                                               unsigned* s_overflow) {
   const unsigned lane = threadIdx.x & 63;
   qcount -= n;
+#ifdef SKC_ABL_NODRAIN  // (timing ablation only: the deferred keys are pushed and then dropped)
+  return;
+#endif
   if (lane < n) {
     const u64 key = q[qcount + lane];
     unsigned slot = skc_step(skc_home(skc_hash(key)), 1);
